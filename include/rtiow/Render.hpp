@@ -1,0 +1,121 @@
+// rtiow/Render.hpp — the reference's free functions ray_color() and random_scene() (reference:
+// main.cpp:83-101 and 116-158) for the host, and render_image(): the GPU replacement of the
+// "Image Generation" scope (main.cpp:62-78) behind the same scene objects.
+#pragma once
+
+#include "Camera.hpp"
+#include "Color.hpp"
+#include "Flatten.hpp"
+#include "HittableList.hpp"
+#include "Material.hpp"
+#include "Sphere3.hpp"
+#include "rtk.h"
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+// CPU radiance along one ray, at most `depth` segments.  The reference recurses and multiplies the
+// material colours from the far end of the path back (c1*(c2*(...*sky))); this walks the path
+// forward, remembers the colours, and folds them in that same order.
+inline Color ray_color(const Ray3& r, const Hittable& world, int depth) {
+    std::vector<Color> albedo;
+    Ray3 ray = r;
+    Color tail{0.0f, 0.0f, 0.0f};
+    for (int left = depth;; --left) {
+        if (left <= 0) break;                                   // bounce limit: no light
+        hit_record rec{};
+        if (!world.hit(ray, 0.001f, infinity, rec)) {
+            const Vector3 dir = unit_vector(ray.direction());
+            const float t = 0.5f * (dir.y() + 1.0f);
+            tail = (1.0f - t) * Color(1.0f, 1.0f, 1.0f) + t * Color(0.5f, 0.7f, 1.0f);
+            break;
+        }
+        Ray3 scattered{};
+        if (!rec.material.scatter(ray, rec, scattered)) break;  // absorbed
+        albedo.push_back(rec.material.color);
+        ray = scattered;
+    }
+    for (auto it = albedo.rbegin(); it != albedo.rend(); ++it) tail = *it * tail;
+    return tail;
+}
+
+// Book-1 final scene: ground, a 22 x 22 grid of small random spheres, three big ones.
+inline HittableList random_scene() {
+    HittableList world{};
+    const auto sphere = [&world](Point3 c, float r, const Material& m) { world.add(std::make_shared<Sphere3>(c, r, m)); };
+    sphere(Point3{0.0f, -1000.0f, 0.0f}, 1000.0f, make_lambertian(MaterialDesc{Color{0.5f, 0.5f, 0.5f}}));
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            const float choose_mat = random_float();
+            const float cx = a + 0.9f * random_float();
+            const float cz = b + 0.9f * random_float();
+            const Point3 center{cx, 0.2f, cz};
+            if (!((center - Point3{4.0f, 0.2f, 0.0f}).length() > 0.9f)) continue;
+            MaterialDesc desc{};
+            Material material{};
+            if (choose_mat < 0.8f) {
+                const Color c1 = Color::random();
+                const Color c2 = Color::random();
+                desc.color = c1 * c2;
+                material = make_lambertian(desc);
+            } else if (choose_mat < 0.95f) {
+                desc.color = Color::random(0.5f, 1.0f);
+                desc.roughness = random_float(0.0f, 0.5f);
+                desc.metallic = 1.0f;
+                material = make_metal(desc);
+            } else {
+                desc.refractionIndex = 1.5f;
+                desc.color = Color{1.0f, 1.0f, 1.0f};
+                desc.roughness = 0.0f;
+                material = make_dielectric(desc);
+            }
+            sphere(center, 0.2f, material);
+        }
+    }
+    sphere(Point3{0.0f, 1.0f, 0.0f}, 1.0f, make_dielectric(MaterialDesc{Color{1.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.5f}));
+    sphere(Point3{-4.0f, 1.0f, 0.0f}, 1.0f, make_lambertian(MaterialDesc{Color{0.4f, 0.2f, 0.1f}}));
+    sphere(Point3{4.0f, 1.0f, 0.0f}, 1.0f, make_metal(MaterialDesc{Color{0.7f, 0.6f, 0.5f}, 0.0f, 1.0f}));
+    return world;
+}
+
+namespace rtiow {
+
+struct RenderResult {
+    std::vector<float> rgb_sum;   // [height][width][3], row 0 = top image row
+    rtk_stats stats{};
+};
+
+// GPU render of `world` seen by `camera`: what main.cpp:64-76 computes, as per-pixel colour sums.
+// Throws std::runtime_error with rtk_last_error() on failure (there is no CPU fallback).
+inline RenderResult render_image(const Hittable& world, const Camera& camera, int image_width, int image_height, int samples_per_pixel,
+                                 int max_depth, uint64_t seed = 0, int device = 0) {
+    const FlatScene flat = flatten(world);
+    rtk_context* ctx = nullptr;
+    const auto check = [&ctx](int status, const char* what) {
+        if (status == RTK_OK) return;
+        const std::string msg = std::string(what) + ": " + rtk_last_error();
+        if (ctx) rtk_context_destroy(ctx);
+        throw std::runtime_error(msg);
+    };
+    check(rtk_context_create(device, &ctx), "rtk_context_create");
+    const rtk_scene view = flat.view();
+    check(rtk_set_scene(ctx, &view), "rtk_set_scene");
+    rtk_params p{};
+    p.width = image_width;
+    p.height = image_height;
+    p.spp = samples_per_pixel;
+    p.max_depth = max_depth;
+    p.seed = seed;
+    p.t_min = 0.001f;
+    p.world_size = 1;
+    const rtk_camera cam = camera.export_fields();
+    RenderResult out;
+    out.rgb_sum.resize(static_cast<size_t>(image_width) * image_height * 3);
+    check(rtk_render(ctx, &cam, &p, out.rgb_sum.data(), &out.stats), "rtk_render");
+    rtk_context_destroy(ctx);
+    return out;
+}
+
+} // namespace rtiow

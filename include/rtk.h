@@ -1,0 +1,185 @@
+/* include/rtk.h — C ABI of librtk.so, the MI355X (gfx950) replacement for the reference's
+ * "Image Generation" scope.
+ *
+ * The reference (cugone/RayTracingInOneWeekend, branch master) has NO plugin / operator / FFI
+ * interface.  The seam this library fills is the block guarded by
+ * PROFILE_LOG_SCOPE("Image Generation"), RayTracingInOneWeekend/main.cpp:62-78: its inputs are the
+ * already-built HittableList (main.cpp:45), the Camera (main.cpp:54) and the four CLI integers
+ * (main.cpp:24-41); its output is the per-pixel colour sum handed to write_color_binary
+ * (main.cpp:74, Color.hpp:28-48).  Each entry point below cites the reference code it replaces.
+ * File:line citations are relative to /root/reference/RayTracingInOneWeekend/.
+ *
+ * Conventions: plain C, POD structs, caller owns every host pointer for the duration of a call,
+ * the library owns all device memory of a context.  Every function returns RTK_OK (0) or a negative
+ * rtk_status; nothing throws.  rtk_last_error() returns a thread-local message for the last failure.
+ * A context is used by one host thread at a time.  There is no CPU fallback: without a usable HIP
+ * device rtk_context_create fails with RTK_ERR_NO_DEVICE.
+ */
+#ifndef RTK_H
+#define RTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtk_status {
+    RTK_OK = 0,
+    RTK_ERR_BAD_ARG = -1,    /* null pointer, non-positive size, tile not 64 pixels, ... */
+    RTK_ERR_NO_DEVICE = -2,  /* no HIP device / device index out of range */
+    RTK_ERR_HIP = -3,        /* a HIP runtime call failed; see rtk_last_error() */
+    RTK_ERR_NO_SCENE = -4,   /* render/intersect before rtk_set_scene */
+    RTK_ERR_TOO_LARGE = -5   /* size beyond a documented limit */
+} rtk_status;
+
+/* Material::Type, Material.hpp:10-15 (enum order). */
+enum { RTK_MAT_NONE = 0, RTK_MAT_LAMBERTIAN = 1, RTK_MAT_METAL = 2, RTK_MAT_GLASS = 3 };
+
+/* Flattened HittableList of Sphere3 (HittableList.hpp:27, Sphere3.hpp:22-24, Material.hpp:19-24),
+ * structure-of-arrays, LIST ORDER PRESERVED (the closest-hit tie rule depends on it,
+ * HittableList.hpp:34-38 with Sphere3.hpp:43).  `color` is Material::color, the multiplier
+ * ray_color uses (main.cpp:93); Material::attenuation is never read on the path and is not carried. */
+typedef struct rtk_scene {
+    int32_t n;
+    const float* cx;
+    const float* cy;
+    const float* cz;
+    const float* radius;
+    const float* mat_r;
+    const float* mat_g;
+    const float* mat_b;
+    const float* roughness;
+    const float* metallic;
+    const float* ior;          /* Material::refractionIndex */
+    const int32_t* mat_type;   /* RTK_MAT_* */
+} rtk_scene;
+
+/* The eight private fields of Camera (Camera.hpp:32-39) as the constructor leaves them
+ * (Camera.hpp:8-23). */
+typedef struct rtk_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float lens_radius;
+} rtk_camera;
+
+/* Inputs of the pixel/sample loops, main.cpp:24-41 and 64-76. */
+typedef struct rtk_params {
+    int32_t width;        /* image_width  */
+    int32_t height;       /* image_height */
+    int32_t spp;          /* samples_per_pixel */
+    int32_t max_depth;    /* max_depth */
+    uint64_t seed;        /* key of the counter-based RNG that replaces MathUtils.hpp:15-25 */
+    float t_min;          /* 0.001f at main.cpp:90 */
+    int32_t rank;         /* this process renders tiles i with i % world_size == rank ... */
+    int32_t world_size;   /* ... of the row-major grid of tile_w x tile_h pixel tiles */
+    int32_t tile_w;       /* tile_w * tile_h must be 64 (one wavefront of pixels); 0,0 -> 8 x 8 */
+    int32_t tile_h;
+    int32_t run_len;      /* samples a lane accumulates in fp32 before one fixed-point add; 0 -> default */
+} rtk_params;
+
+/* What one render did.  `rays` counts ray SEGMENTS = calls of HittableList::hit (main.cpp:90),
+ * primary rays included, counted by the kernel itself. */
+typedef struct rtk_stats {
+    uint64_t rays;
+    uint64_t samples;
+    uint64_t sphere_tests;     /* rays x scene size: the filter tests every sphere for every segment */
+    uint64_t exact_tests;      /* candidates re-tested with the reference's exact arithmetic */
+    uint64_t lane_slots;       /* 64 x wavefront passes through the intersection loop */
+    float kernel_ms;           /* HIP-event time of the render kernel alone */
+    float total_ms;            /* clear + render + finalise (+ copy-out for host outputs) */
+} rtk_stats;
+
+typedef struct rtk_context rtk_context;
+
+/* Number of visible HIP devices (0 when there is none). */
+int rtk_device_count(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* rtk_last_error(void);
+
+/* Persistent state on one device: stream, scene buffers, accumulators.  Replaces nothing in the
+ * reference (which has no device); it exists so that frames after the first pay no allocation. */
+int rtk_context_create(int device, rtk_context** out);
+void rtk_context_destroy(rtk_context* ctx);
+
+/* Use an existing HIP stream (a hipStream_t passed as void*) for all work of the context;
+ * NULL selects the context's own stream.  For callers that own device memory, e.g. torch. */
+int rtk_context_set_stream(rtk_context* ctx, void* hip_stream);
+
+/* Upload the flattened world.  Replaces the traversal state HittableList::hit walks
+ * (HittableList.hpp:27,34): precomputes, bit-identically to the reference's own fp32 operations,
+ * radius*radius (Sphere3.hpp:35) and 1/radius (Vector3.cpp:35-37 via Sphere3.hpp:54). */
+int rtk_set_scene(rtk_context* ctx, const rtk_scene* scene);
+
+/* Number of tiles rank `rank` of `world_size` owns for a width x height image. */
+int64_t rtk_local_tile_count(int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, int32_t rank,
+                             int32_t world_size);
+
+/* main.cpp:64-76 for the tiles of p->rank: per-pixel fp32 colour sums over spp samples, written to
+ * DEVICE memory `d_tile_sums` as [local tile][tile_h][tile_w][3] floats (local tile k is global tile
+ * k * world_size + rank).  Asynchronous on the context's stream; pixels of edge tiles that fall
+ * outside the image are written as 0.  `stats` may be NULL; when given, the call synchronises. */
+int rtk_render_tiles_device(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
+                            rtk_stats* stats);
+
+/* Scatter gathered tile buffers back to scanline order (row 0 = top image row, i.e. y = H-1, the
+ * order main.cpp:64 emits): `d_gathered` is [world_size][tiles_per_rank_padded][64][3] floats in
+ * DEVICE memory, `d_image` is [height][width][3] floats in DEVICE memory.  Asynchronous. */
+int rtk_deinterleave_device(rtk_context* ctx, const float* d_gathered, int64_t tiles_per_rank_padded,
+                            const rtk_params* p, float* d_image);
+
+/* Whole image on one device into HOST memory: out_rgb_sum is [height][width][3] fp32 colour sums,
+ * row 0 = top row.  Equivalent to the reference's loops main.cpp:64-76 with write_color_binary's
+ * input captured instead of written.  p->rank/world_size must be 0/1 (or 0/0). */
+int rtk_render(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* out_rgb_sum, rtk_stats* stats);
+
+/* write_color_binary (Color.hpp:28-48) for n_pixels RGB sums: sqrt(sum/spp), clamp [0,1],
+ * (uint8_t)(255*x).  DEVICE pointers, asynchronous.  Byte-exact with the reference for equal sums. */
+int rtk_quantise_device(rtk_context* ctx, const float* d_rgb_sum, int64_t n_pixels, int32_t spp, uint8_t* d_rgb_u8);
+
+/* HittableList::hit (HittableList.hpp:30-42) with Sphere3::hit (Sphere3.hpp:31-59) for a batch of
+ * rays against the context's scene: HOST arrays; rays are 6 floats (origin, direction; direction
+ * NOT normalised, Ray3.hpp:14).  out_hit[i] in {0,1}; out_index[i] = list index of the winning
+ * sphere or -1; out_t[i] = hit_record::t or 0.  hit and index are bit-exact with the reference,
+ * t is computed with the reference's operation sequence (no FMA contraction, IEEE sqrt and divide). */
+int rtk_intersect_batch(rtk_context* ctx, const float* rays, size_t n, float t_min, float t_max, uint8_t* out_hit,
+                        int32_t* out_index, float* out_t);
+
+/* Same, DEVICE pointers, asynchronous on the context's stream (used by bench/profiling). */
+int rtk_intersect_batch_device(rtk_context* ctx, const float* d_rays, size_t n, float t_min, float t_max,
+                               uint8_t* d_hit, int32_t* d_index, float* d_t);
+
+/* hit_record construction (Sphere3.hpp:51-56, Hittable.hpp:15-18) + Material::scatter
+ * (Material.cpp:6-54) for a batch: ray i hit sphere index[i] at t[i].  The random inputs are supplied
+ * by the caller as 4 uniforms in [0,1) per ray (in rendering they come from the counter-based RNG):
+ * Lambertian maps u[0..1] to a unit vector, Metal maps u[0..2] to a point in the unit ball, Glass
+ * compares the Schlick reflectance with u[3] (evaluated unconditionally; the reference's lazy draw at
+ * Material.cpp:40 is an RNG-stream detail).  HOST arrays.  out7 = scattered origin, direction,
+ * and 1.0/0.0 for scatter's return value. */
+int rtk_scatter_batch(rtk_context* ctx, const float* rays, const int32_t* index, const float* t, const float* u4,
+                      size_t n, float* out7);
+
+/* Camera::get_ray (Camera.hpp:25-29) + the jitter of main.cpp:69-70 exactly as the render kernel
+ * evaluates them for (pixel x, row-from-top, sample): HOST output of n rays (6 floats) for the
+ * given integer triples xyz[3*i..]; for tests. */
+int rtk_primary_rays(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, const int32_t* xys, size_t n,
+                     float* out_rays);
+
+/* The counter-based generator itself (Philox4x32-10): out4[4*i..] for counters ctr4[4*i..] under
+ * p->seed; HOST arrays; for known-answer tests. */
+int rtk_philox_batch(rtk_context* ctx, uint64_t seed, const uint32_t* ctr4, size_t n, uint32_t* out4);
+
+/* Block until everything queued on the context's stream has finished. */
+int rtk_synchronize(rtk_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_H */

@@ -1,0 +1,735 @@
+// rtk.hip — kernels and C ABI of librtk.so (see include/rtk.h for the contract and the reference
+// citations of every entry point).  gfx950 only; compiled with -ffp-contract=off (rtk_device.hpp).
+#include "rtk_device.hpp"
+
+#include "../../include/rtk.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+using namespace rtk;
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+
+struct RenderArgs {
+    SceneDev scene;
+    CameraDev cam;
+    int32_t W, H, spp, max_depth;
+    uint32_t seed_lo, seed_hi;
+    float t_min;
+    int32_t tile_w, tile_h, tiles_x;
+    int32_t rank, world;
+    int32_t n_local_tiles;
+    int32_t run_len, n_runs;
+    uint32_t total_packets;
+    unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
+    uint32_t* queue;             // packet counter
+    unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
+};
+
+// Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists.
+template <bool LDS>
+__device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
+    Intersector<LDS> it;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned char* p = smem;
+    if (LDS) {
+        float4* lf = reinterpret_cast<float4*>(p);
+        float4* le = lf + sc.npad;
+        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) {
+            lf[i] = sc.filt[i];
+            le[i] = sc.exact[i];
+        }
+        it.filt = lf;
+        it.exact = le;
+        p += static_cast<size_t>(sc.npad) * 32;
+    } else {
+        it.filt = sc.filt;
+        it.exact = sc.exact;
+    }
+    it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
+    it.n = sc.n;
+    it.nwords = sc.npad / 32;
+    it.lane = lane;
+    __syncthreads();
+    return it;
+}
+
+static size_t lds_bytes(bool lds, int npad) { return (lds ? static_cast<size_t>(npad) * 32 : 0) + kWavesPerBlock * kListCap * kWave * 2; }
+
+// Persistent wavefronts.  A packet = one 64-pixel tile x one run of `run_len` samples; a wavefront
+// draws packets from a global counter and hands the packet's 64 (pixel, run) units to whichever of
+// its lanes is free, so lanes whose path ended (sky, absorbed, depth exhausted) start the next sample
+// at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
+// run in fp32 and adds the run total once, as 32.32 fixed point, to the pixel's accumulator: integer
+// adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
+template <bool LDS>
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);
+    const int lane = isect.lane;
+    const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
+
+    // lane state
+    Ray ray = {};
+    V3 thr = {0, 0, 0}, acc = {0, 0, 0};
+    bool alive = false, has_unit = false;
+    int depth_left = 0, unit_left = 0;
+    uint32_t pixel = 0, slot = 0, sample = 0, bounce = 0;
+    int px = 0, prow = 0;
+    uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
+    // wave state (uniform)
+    int pk_pos = kWave, pk_lt = 0, pk_run = 0;
+    bool queue_empty = false;
+    uint32_t wave_passes = 0;
+
+    for (;;) {
+        // ---- lanes without a live path: next sample of the unit, or retire the unit ----
+        bool start = false, need = false;
+        if (!alive) {
+            if (has_unit && unit_left > 0) {
+                --unit_left;
+                ++sample;
+                start = true;
+            } else {
+                if (has_unit) {
+                    // 32.32 fixed point; NaN contributes 0, magnitudes are clamped to +-2^30.
+                    const float lim = 0x1p30f;
+                    const float fr = fminf(fmaxf(acc.x, -lim), lim), fg = fminf(fmaxf(acc.y, -lim), lim), fb = fminf(fmaxf(acc.z, -lim), lim);
+                    const long long qr = (acc.x == acc.x) ? __double2ll_rn(static_cast<double>(fr) * 4294967296.0) : 0;
+                    const long long qg = (acc.y == acc.y) ? __double2ll_rn(static_cast<double>(fg) * 4294967296.0) : 0;
+                    const long long qb = (acc.z == acc.z) ? __double2ll_rn(static_cast<double>(fb) * 4294967296.0) : 0;
+                    unsigned long long* dst = A.accum + static_cast<size_t>(slot) * 3;
+                    atomicAdd(dst + 0, static_cast<unsigned long long>(qr));
+                    atomicAdd(dst + 1, static_cast<unsigned long long>(qg));
+                    atomicAdd(dst + 2, static_cast<unsigned long long>(qb));
+                    has_unit = false;
+                }
+                need = true;
+            }
+        }
+        // ---- hand out units of the wave's packet; draw a new packet when it runs dry ----
+        for (;;) {
+            const uint64_t nb = ballot(need);
+            if (nb == 0ull) break;
+            if (pk_pos >= kWave) {
+                if (queue_empty) break;
+                uint32_t q = 0;
+                if (lane == 0) q = atomicAdd(A.queue, 1u);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q >= A.total_packets) {
+                    queue_empty = true;
+                    break;
+                }
+                pk_run = static_cast<int>(q / static_cast<uint32_t>(A.n_local_tiles));
+                pk_lt = static_cast<int>(q % static_cast<uint32_t>(A.n_local_tiles));
+                pk_pos = 0;
+            }
+            const int avail = kWave - pk_pos;
+            const int r = lane_prefix(nb);
+            if (need && r < avail) {
+                const int k = pk_pos + r;
+                const int gt = pk_lt * A.world + A.rank;
+                const int tx = gt % A.tiles_x, ty = gt / A.tiles_x;
+                px = tx * A.tile_w + k % A.tile_w;
+                prow = ty * A.tile_h + k / A.tile_w;
+                if (px < A.W && prow < A.H) {
+                    pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
+                    slot = static_cast<uint32_t>(pk_lt) * kWave + static_cast<uint32_t>(k);
+                    sample = static_cast<uint32_t>(pk_run) * static_cast<uint32_t>(A.run_len);
+                    const int left = A.spp - static_cast<int>(sample);
+                    unit_left = (left < A.run_len ? left : A.run_len) - 1;
+                    acc = {0, 0, 0};
+                    has_unit = true;
+                    start = true;
+                    need = false;
+                }
+                // a unit that falls outside the image is dropped; the lane asks again
+            }
+            const int took = __popcll(nb);
+            pk_pos += took < avail ? took : avail;
+        }
+        // ---- primary rays (main.cpp:69-71) ----
+        if (start) {
+            const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
+            const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+            ray = primary_ray(A.cam, px, prow, A.W, A.H, u);
+            thr = {1.0f, 1.0f, 1.0f};
+            depth_left = A.max_depth;
+            bounce = 0;
+            alive = depth_left > 0;   // main.cpp:87-89: depth <= 0 gathers no light and traces nothing
+            ++n_samp;
+        }
+        if (!wave_any(alive)) {
+            if (!wave_any(has_unit)) break;
+            continue;
+        }
+        // ---- one segment: HittableList::hit (main.cpp:90) ----
+        float t;
+        int idx;
+        isect.closest_hit(ray, alive, A.t_min, std::numeric_limits<float>::infinity(), t, idx, n_exact);
+        ++wave_passes;
+        if (alive) {
+            ++n_seg;
+            if (idx < 0) {
+                acc = acc + thr * sky(ray.d);            // main.cpp:98-100
+                alive = false;
+            } else {
+                ++bounce;
+                const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, bounce, 0u), key);
+                const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+                const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
+                Ray out;
+                const bool ok = hit_and_scatter(ray, t, ex, m0, m1, u, out);
+                thr = thr * V3{m0.x, m0.y, m0.z};        // main.cpp:93 (running product)
+                ray = out;
+                --depth_left;
+                alive = ok && depth_left > 0;            // main.cpp:95 / 87-89: absorbed or out of depth -> black
+            }
+        }
+    }
+    atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
+    atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
+    atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
+    if (lane == 0) atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
+}
+
+// accumulators -> fp32 sums, and clear them for the next frame.
+__global__ void finalize_kernel(unsigned long long* accum, float* out, size_t n) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i < n) {
+        const long long q = static_cast<long long>(accum[i]);
+        out[i] = static_cast<float>(static_cast<double>(q) * (1.0 / 4294967296.0));
+        accum[i] = 0ull;
+    }
+}
+
+// [world][tiles_per_rank_padded][64][3] -> [H][W][3]
+__global__ void deinterleave_kernel(const float* g, long long tprp, int W, int H, int tile_w, int tile_h, int tiles_x, int world, float* img) {
+    const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (p >= static_cast<long long>(W) * H) return;
+    const int x = static_cast<int>(p % W), row = static_cast<int>(p / W);
+    const int tx = x / tile_w, ty = row / tile_h;
+    const int gt = ty * tiles_x + tx;
+    const int k = (row % tile_h) * tile_w + (x % tile_w);
+    const long long src = ((static_cast<long long>(gt % world) * tprp + gt / world) * kWave + k) * 3;
+    img[p * 3 + 0] = g[src + 0];
+    img[p * 3 + 1] = g[src + 1];
+    img[p * 3 + 2] = g[src + 2];
+}
+
+// Color.hpp:28-48.
+__global__ void quantise_kernel(const float* sums, long long n, int spp, uint8_t* out) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const float scale = 1.0f / static_cast<float>(spp);
+    float v = __builtin_sqrtf(scale * sums[i]);
+    v = (v < 0.0f) ? 0.0f : (1.0f < v) ? 1.0f : v;   // std::clamp semantics, NaN passes through
+    out[i] = static_cast<uint8_t>(static_cast<int>(255.0f * v));
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kBlockThreads) void intersect_kernel(const SceneDev sc, const float* rays, size_t n, float t_min, float t_max,
+                                                                   uint8_t* out_hit, int32_t* out_index, float* out_t) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Intersector<LDS> isect = make_intersector<LDS>(sc, smem);
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    // whole wavefronts iterate together (closest_hit uses wave-level votes)
+    const size_t n_round = (n + kWave - 1) / kWave * kWave;
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n_round; i += stride) {
+        const bool active = i < n;
+        Ray r = {};
+        if (active) {
+            const float* q = rays + 6 * i;
+            r = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+        }
+        float t;
+        int idx;
+        uint32_t n_exact = 0;
+        isect.closest_hit(r, active, t_min, t_max, t, idx, n_exact);
+        if (active) {
+            out_hit[i] = idx >= 0 ? 1 : 0;
+            out_index[i] = idx;
+            out_t[i] = idx >= 0 ? t : 0.0f;
+        }
+    }
+}
+
+__global__ void scatter_kernel(const SceneDev sc, const float* rays, const int32_t* index, const float* t, const float* u4, size_t n, float* out7) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const float* q = rays + 6 * i;
+    const Ray in = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+    const int idx = index[i];
+    const float u[4] = {u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3]};
+    Ray out;
+    const bool ok = hit_and_scatter(in, t[i], sc.exact[idx], sc.mat0[idx], sc.mat1[idx], u, out);
+    float* o = out7 + 7 * i;
+    o[0] = out.o.x; o[1] = out.o.y; o[2] = out.o.z; o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z;
+    o[6] = ok ? 1.0f : 0.0f;
+}
+
+__global__ void primary_kernel(const CameraDev cam, int W, int H, uint32_t seed_lo, uint32_t seed_hi, const int32_t* xys, size_t n, float* out) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const int x = xys[3 * i], row = xys[3 * i + 1], s = xys[3 * i + 2];
+    const uint32_t pixel = static_cast<uint32_t>(row) * static_cast<uint32_t>(W) + static_cast<uint32_t>(x);
+    const uint4 rnd = philox4x32_10(make_uint4(pixel, static_cast<uint32_t>(s), 0u, 0u), make_uint2(seed_lo, seed_hi));
+    const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+    const Ray r = primary_ray(cam, x, row, W, H, u);
+    float* o = out + 6 * i;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+__global__ void philox_kernel(uint32_t seed_lo, uint32_t seed_hi, const uint32_t* ctr4, size_t n, uint32_t* out4) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = philox4x32_10(make_uint4(ctr4[4 * i], ctr4[4 * i + 1], ctr4[4 * i + 2], ctr4[4 * i + 3]), make_uint2(seed_lo, seed_hi));
+    out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+}
+
+// =================================================================================================
+// Host side of the C ABI
+// =================================================================================================
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        const hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(RTK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct rtk_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    int n_cu = 0;
+    int blocks_per_cu[2] = {0, 0};   // [LDS]
+    SceneDev scene = {};
+    bool have_scene = false;
+    DevBuf filt, exact, mat0, mat1;
+    DevBuf accum;        // fixed-point accumulators
+    size_t accum_zeroed = 0;   // number of accumulators known to be zero
+    DevBuf control;      // queue counter (256 B) + stats
+    DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // batch entry points
+    DevBuf tile_out;     // for rtk_render (host output)
+    DevBuf image_out;
+};
+
+static bool use_lds(const rtk_context* c) { return c->scene.n <= kMaxLdsSpheres; }
+
+extern "C" {
+
+int rtk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rtk_last_error(void) { return g_err; }
+
+int rtk_context_create(int device, rtk_context** out) {
+    if (!out) return fail(RTK_ERR_BAD_ARG, "rtk_context_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTK_ERR_NO_DEVICE, "no HIP device is visible; librtk has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RTK_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    rtk_context* c = new (std::nothrow) rtk_context();
+    if (!c) return fail(RTK_ERR_HIP, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete c;
+        return fail(RTK_ERR_NO_DEVICE, "device %d is %s; librtk is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    }
+    c->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreate(&c->ev2));
+    HIP_TRY(hipEventCreate(&c->ev3));
+    HIP_TRY(c->control.reserve(512));
+    HIP_TRY(hipMemset(c->control.p, 0, 512));
+    *out = c;
+    return RTK_OK;
+}
+
+void rtk_context_destroy(rtk_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+                      &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out})
+        b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rtk_context_set_stream(rtk_context* c, void* hip_stream) {
+    if (!c) return fail(RTK_ERR_BAD_ARG, "null context");
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return RTK_OK;
+}
+
+int rtk_synchronize(rtk_context* c) {
+    if (!c) return fail(RTK_ERR_BAD_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
+    if (!c || !s) return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null argument");
+    if (s->n <= 0) return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: scene has %d spheres", s->n);
+    if (s->n > 65536 - 32) return fail(RTK_ERR_TOO_LARGE, "rtk_set_scene: %d spheres; candidate lists index spheres with 16 bits", s->n);
+    if (!s->cx || !s->cy || !s->cz || !s->radius || !s->mat_r || !s->mat_g || !s->mat_b || !s->roughness || !s->metallic || !s->ior || !s->mat_type)
+        return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null array");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = s->n, npad = (n + 31) / 32 * 32;
+    std::vector<float4> filt(npad), exact(npad), m0(n), m1(n);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int i = 0; i < npad; ++i) {
+        if (i >= n) {
+            // pad: r^2 term of -inf makes the widened discriminant -inf for every finite ray
+            filt[i] = make_float4(0.f, 0.f, 0.f, -inf);
+            exact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const float cx = s->cx[i], cy = s->cy[i], cz = s->cz[i], r = s->radius[i];
+        volatile float rr_v = r * r;                 // fl(radius*radius), Sphere3.hpp:35 (host compiler must not widen)
+        const float rr = rr_v;
+        exact[i] = make_float4(cx, cy, cz, rr);
+        const float big = 0x1p30f, ar = std::fabs(r);
+        const bool safe = std::fabs(cx) < big && std::fabs(cy) < big && std::fabs(cz) < big && ar > 0x1p-20f && ar < big;
+        // unsafe spheres (NaN/inf/huge/tiny) are candidates for every ray: centre 0, r^2 term +inf
+        filt[i] = safe ? make_float4(cx, cy, cz, rr * kFilterScaleSq) : make_float4(0.f, 0.f, 0.f, inf);
+        m0[i] = make_float4(s->mat_r[i], s->mat_g[i], s->mat_b[i], s->roughness[i]);
+        int32_t ty = s->mat_type[i];
+        float tyf;
+        std::memcpy(&tyf, &ty, 4);
+        volatile float inv_v = 1.0f / r;             // fl(1/radius), Vector3.cpp:36
+        m1[i] = make_float4(s->metallic[i], s->ior[i], tyf, inv_v);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->filt.reserve(sizeof(float4) * npad));
+    HIP_TRY(c->exact.reserve(sizeof(float4) * npad));
+    HIP_TRY(c->mat0.reserve(sizeof(float4) * n));
+    HIP_TRY(c->mat1.reserve(sizeof(float4) * n));
+    HIP_TRY(hipMemcpy(c->filt.p, filt.data(), sizeof(float4) * npad, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->exact.p, exact.data(), sizeof(float4) * npad, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mat0.p, m0.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mat1.p, m1.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
+                static_cast<const float4*>(c->mat1.p), n, npad};
+    c->have_scene = true;
+    // persistent-grid sizing for both kernel flavours at this scene size
+    for (int l = 0; l < 2; ++l) {
+        int nb = 0;
+        const size_t shm = lds_bytes(l == 1, npad);
+        if (l == 1 && !use_lds(c)) { c->blocks_per_cu[l] = 0; continue; }
+        if (l == 1) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm)));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm)));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true>, kBlockThreads, shm));
+        } else {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false>, kBlockThreads, shm));
+        }
+        c->blocks_per_cu[l] = nb > 0 ? nb : 1;
+    }
+    return RTK_OK;
+}
+
+static int norm_tiles(const rtk_params* p, int& tw, int& th) {
+    tw = p->tile_w;
+    th = p->tile_h;
+    if (tw == 0 && th == 0) { tw = 8; th = 8; }
+    if (tw <= 0 || th <= 0 || tw * th != kWave) return fail(RTK_ERR_BAD_ARG, "tile %d x %d: a tile must hold exactly 64 pixels", tw, th);
+    return RTK_OK;
+}
+
+int64_t rtk_local_tile_count(int32_t W, int32_t H, int32_t tile_w, int32_t tile_h, int32_t rank, int32_t world) {
+    if (tile_w == 0 && tile_h == 0) { tile_w = 8; tile_h = 8; }
+    if (W <= 0 || H <= 0 || tile_w <= 0 || tile_h <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
+    const int64_t tiles = static_cast<int64_t>((W + tile_w - 1) / tile_w) * ((H + tile_h - 1) / tile_h);
+    return (tiles - rank + world - 1) / world;
+}
+
+static int default_run_len(int spp) {
+    // long enough that the three fixed-point adds per run are noise, short enough that the units
+    // still in flight when the queue empties are a small tail
+    int r = 8;
+    if (r > spp) r = spp;
+    return r < 1 ? 1 : r;
+}
+
+int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats) {
+    if (!c || !cam || !p || !d_tile_sums) return fail(RTK_ERR_BAD_ARG, "rtk_render_tiles_device: null argument");
+    if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_render_tiles_device: call rtk_set_scene first");
+    if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
+    if (p->spp <= 0) return fail(RTK_ERR_BAD_ARG, "spp must be positive, got %d", p->spp);
+    const int world = p->world_size > 0 ? p->world_size : 1;
+    if (p->rank < 0 || p->rank >= world) return fail(RTK_ERR_BAD_ARG, "rank %d of %d", p->rank, world);
+    int tw, th;
+    if (int e = norm_tiles(p, tw, th)) return e;
+    if (static_cast<int64_t>(p->width) * p->height >= (1ll << 31)) return fail(RTK_ERR_TOO_LARGE, "image has more than 2^31 pixels");
+    HIP_TRY(hipSetDevice(c->device));
+
+    const int tiles_x = (p->width + tw - 1) / tw;
+    const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, p->rank, world);
+    const int run_len = p->run_len > 0 ? (p->run_len < p->spp ? p->run_len : p->spp) : default_run_len(p->spp);
+    const int n_runs = (p->spp + run_len - 1) / run_len;
+    const int64_t packets = nlt * n_runs;
+    if (packets >= (1ll << 32) - (1ll << 20)) return fail(RTK_ERR_TOO_LARGE, "%lld packets exceed the 32-bit queue", static_cast<long long>(packets));
+    const size_t n_acc = static_cast<size_t>(nlt) * kWave * 3;
+    if (nlt == 0) return RTK_OK;
+
+    if (n_acc * 8 > c->accum.cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(c->accum.reserve(n_acc * 8));
+        c->accum_zeroed = 0;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (c->accum_zeroed < n_acc) {
+        HIP_TRY(hipMemsetAsync(c->accum.p, 0, c->accum.cap, c->stream));
+        c->accum_zeroed = c->accum.cap / 8;
+    }
+    HIP_TRY(hipMemsetAsync(c->control.p, 0, 512, c->stream));
+
+    RenderArgs A;
+    A.scene = c->scene;
+    std::memcpy(&A.cam, cam, sizeof(float) * 22);
+    A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_depth = p->max_depth;
+    A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
+    A.t_min = p->t_min;
+    A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
+    A.rank = p->rank; A.world = world;
+    A.n_local_tiles = static_cast<int32_t>(nlt);
+    A.run_len = run_len; A.n_runs = n_runs;
+    A.total_packets = static_cast<uint32_t>(packets);
+    A.accum = static_cast<unsigned long long*>(c->accum.p);
+    A.queue = static_cast<uint32_t*>(c->control.p);
+    A.stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->control.p) + 256);
+
+    const bool lds = use_lds(c);
+    const size_t shm = lds_bytes(lds, c->scene.npad);
+    int64_t grid = static_cast<int64_t>(c->n_cu) * c->blocks_per_cu[lds ? 1 : 0];
+    const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (lds)
+        hipLaunchKernelGGL(render_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev2, c->stream));
+    const unsigned fb = static_cast<unsigned>((n_acc + 255) / 256);
+    hipLaunchKernelGGL(finalize_kernel, dim3(fb), dim3(256), 0, c->stream, static_cast<unsigned long long*>(c->accum.p), d_tile_sums, n_acc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev3, c->stream));
+    if (stats) {
+        unsigned long long h[4];
+        HIP_TRY(hipMemcpyAsync(h, A.stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        stats->rays = h[0];
+        stats->samples = h[1];
+        stats->sphere_tests = h[0] * static_cast<uint64_t>(c->scene.n);
+        stats->exact_tests = h[2];
+        stats->lane_slots = h[3] * kWave;
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, c->ev1, c->ev2));
+        HIP_TRY(hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
+    }
+    return RTK_OK;
+}
+
+int rtk_deinterleave_device(rtk_context* c, const float* d_gathered, int64_t tprp, const rtk_params* p, float* d_image) {
+    if (!c || !d_gathered || !p || !d_image) return fail(RTK_ERR_BAD_ARG, "rtk_deinterleave_device: null argument");
+    int tw, th;
+    if (int e = norm_tiles(p, tw, th)) return e;
+    const int world = p->world_size > 0 ? p->world_size : 1;
+    if (p->width <= 0 || p->height <= 0) return fail(RTK_ERR_BAD_ARG, "image %d x %d", p->width, p->height);
+    if (tprp < rtk_local_tile_count(p->width, p->height, tw, th, 0, world)) return fail(RTK_ERR_BAD_ARG, "tiles_per_rank_padded %lld is too small", static_cast<long long>(tprp));
+    HIP_TRY(hipSetDevice(c->device));
+    const long long np = static_cast<long long>(p->width) * p->height;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, c->stream, d_gathered, static_cast<long long>(tprp),
+                       p->width, p->height, tw, th, (p->width + tw - 1) / tw, world, d_image);
+    HIP_TRY(hipGetLastError());
+    return RTK_OK;
+}
+
+int rtk_render(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* out, rtk_stats* stats) {
+    if (!c || !cam || !p || !out) return fail(RTK_ERR_BAD_ARG, "rtk_render: null argument");
+    if (p->world_size > 1 || p->rank != 0) return fail(RTK_ERR_BAD_ARG, "rtk_render renders the whole image: rank/world_size must be 0/1");
+    int tw, th;
+    if (int e = norm_tiles(p, tw, th)) return e;
+    if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
+    HIP_TRY(hipSetDevice(c->device));
+    rtk_params q = *p;
+    q.world_size = 1;
+    q.rank = 0;
+    const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, 0, 1);
+    const size_t np = static_cast<size_t>(p->width) * p->height;
+    HIP_TRY(c->tile_out.reserve(static_cast<size_t>(nlt) * kWave * 3 * sizeof(float)));
+    HIP_TRY(c->image_out.reserve(np * 3 * sizeof(float)));
+    rtk_stats st;
+    if (int e = rtk_render_tiles_device(c, cam, &q, static_cast<float*>(c->tile_out.p), &st)) return e;
+    if (int e = rtk_deinterleave_device(c, static_cast<const float*>(c->tile_out.p), nlt, &q, static_cast<float*>(c->image_out.p))) return e;
+    HIP_TRY(hipMemcpyAsync(out, c->image_out.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) *stats = st;
+    return RTK_OK;
+}
+
+int rtk_quantise_device(rtk_context* c, const float* d_sum, int64_t n_pixels, int32_t spp, uint8_t* d_u8) {
+    if (!c || !d_sum || !d_u8) return fail(RTK_ERR_BAD_ARG, "rtk_quantise_device: null argument");
+    if (n_pixels <= 0 || spp <= 0) return fail(RTK_ERR_BAD_ARG, "rtk_quantise_device: n_pixels %lld, spp %d", static_cast<long long>(n_pixels), spp);
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n = n_pixels * 3;
+    hipLaunchKernelGGL(quantise_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, c->stream, d_sum, n, spp, d_u8);
+    HIP_TRY(hipGetLastError());
+    return RTK_OK;
+}
+
+int rtk_intersect_batch_device(rtk_context* c, const float* d_rays, size_t n, float t_min, float t_max, uint8_t* d_hit, int32_t* d_index, float* d_t) {
+    if (!c || !d_rays || !d_hit || !d_index || !d_t) return fail(RTK_ERR_BAD_ARG, "rtk_intersect_batch_device: null argument");
+    if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_intersect_batch: call rtk_set_scene first");
+    if (n == 0) return RTK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool lds = use_lds(c);
+    const size_t shm = lds_bytes(lds, c->scene.npad);
+    size_t grid = (n + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = static_cast<size_t>(c->n_cu) * (c->blocks_per_cu[lds ? 1 : 0] > 0 ? c->blocks_per_cu[lds ? 1 : 0] : 1);
+    if (grid > cap) grid = cap;
+    if (lds)
+        hipLaunchKernelGGL(intersect_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t);
+    else
+        hipLaunchKernelGGL(intersect_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t);
+    HIP_TRY(hipGetLastError());
+    return RTK_OK;
+}
+
+int rtk_intersect_batch(rtk_context* c, const float* rays, size_t n, float t_min, float t_max, uint8_t* out_hit, int32_t* out_index, float* out_t) {
+    if (!c || !out_hit || !out_index || !out_t || (!rays && n)) return fail(RTK_ERR_BAD_ARG, "rtk_intersect_batch: null argument");
+    if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_intersect_batch: call rtk_set_scene first");
+    if (n == 0) return RTK_OK;   // empty batch: nothing to do
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch_a.reserve(n * 6 * sizeof(float)));
+    HIP_TRY(c->scratch_b.reserve(n));
+    HIP_TRY(c->scratch_c.reserve(n * sizeof(int32_t)));
+    HIP_TRY(c->scratch_d.reserve(n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->scratch_a.p, rays, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (int e = rtk_intersect_batch_device(c, static_cast<const float*>(c->scratch_a.p), n, t_min, t_max, static_cast<uint8_t*>(c->scratch_b.p),
+                                           static_cast<int32_t*>(c->scratch_c.p), static_cast<float*>(c->scratch_d.p)))
+        return e;
+    HIP_TRY(hipMemcpyAsync(out_hit, c->scratch_b.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_index, c->scratch_c.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_t, c->scratch_d.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+int rtk_scatter_batch(rtk_context* c, const float* rays, const int32_t* index, const float* t, const float* u4, size_t n, float* out7) {
+    if (!c || !out7 || ((!rays || !index || !t || !u4) && n)) return fail(RTK_ERR_BAD_ARG, "rtk_scatter_batch: null argument");
+    if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scatter_batch: call rtk_set_scene first");
+    if (n == 0) return RTK_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (index[i] < 0 || index[i] >= c->scene.n) return fail(RTK_ERR_BAD_ARG, "rtk_scatter_batch: index[%zu] = %d outside the scene (%d spheres)", i, index[i], c->scene.n);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch_a.reserve(n * 6 * sizeof(float)));
+    HIP_TRY(c->scratch_b.reserve(n * sizeof(int32_t)));
+    HIP_TRY(c->scratch_c.reserve(n * sizeof(float)));
+    HIP_TRY(c->scratch_d.reserve(n * 4 * sizeof(float)));
+    HIP_TRY(c->scratch_e.reserve(n * 7 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->scratch_a.p, rays, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_b.p, index, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_c.p, t, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch_d.p, u4, n * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(scatter_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, c->stream, c->scene, static_cast<const float*>(c->scratch_a.p),
+                       static_cast<const int32_t*>(c->scratch_b.p), static_cast<const float*>(c->scratch_c.p), static_cast<const float*>(c->scratch_d.p), n,
+                       static_cast<float*>(c->scratch_e.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out7, c->scratch_e.p, n * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+int rtk_primary_rays(rtk_context* c, const rtk_camera* cam, const rtk_params* p, const int32_t* xys, size_t n, float* out_rays) {
+    if (!c || !cam || !p || !out_rays || (!xys && n)) return fail(RTK_ERR_BAD_ARG, "rtk_primary_rays: null argument");
+    if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d", p->width, p->height);
+    if (n == 0) return RTK_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (xys[3 * i] < 0 || xys[3 * i] >= p->width || xys[3 * i + 1] < 0 || xys[3 * i + 1] >= p->height || xys[3 * i + 2] < 0)
+            return fail(RTK_ERR_BAD_ARG, "rtk_primary_rays: triple %zu outside the image", i);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch_a.reserve(n * 3 * sizeof(int32_t)));
+    HIP_TRY(c->scratch_e.reserve(n * 6 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->scratch_a.p, xys, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CameraDev cd;
+    std::memcpy(&cd, cam, sizeof(float) * 22);
+    hipLaunchKernelGGL(primary_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, c->stream, cd, p->width, p->height, static_cast<uint32_t>(p->seed),
+                       static_cast<uint32_t>(p->seed >> 32), static_cast<const int32_t*>(c->scratch_a.p), n, static_cast<float*>(c->scratch_e.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rays, c->scratch_e.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+int rtk_philox_batch(rtk_context* c, uint64_t seed, const uint32_t* ctr4, size_t n, uint32_t* out4) {
+    if (!c || !out4 || (!ctr4 && n)) return fail(RTK_ERR_BAD_ARG, "rtk_philox_batch: null argument");
+    if (n == 0) return RTK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch_a.reserve(n * 16));
+    HIP_TRY(c->scratch_e.reserve(n * 16));
+    HIP_TRY(hipMemcpyAsync(c->scratch_a.p, ctr4, n * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(philox_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, c->stream, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32),
+                       static_cast<const uint32_t*>(c->scratch_a.p), n, static_cast<uint32_t*>(c->scratch_e.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out4, c->scratch_e.p, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+} // extern "C"

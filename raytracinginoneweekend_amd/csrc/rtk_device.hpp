@@ -1,0 +1,297 @@
+// rtk_device.hpp — device-side building blocks of the MI355X path tracer (gfx950, wave64).
+//
+// This translation unit is compiled with -ffp-contract=off: every `a*b + c` below is two rounded
+// fp32 operations exactly as in the reference (which is built without FMA contraction, SURVEY.md §7
+// hard part 1); fused multiply-adds appear only where `fmaf` is written explicitly (the filter).
+// IEEE-correct sqrt and divide are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt) and
+// f32 denormals are preserved (hipcc default), matching x86-64 SSE arithmetic.
+//
+// Reference citations are relative to /root/reference/RayTracingInOneWeekend/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kBlockThreads = 256;   // 4 waves per workgroup, one per SIMD
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+constexpr int kListCap = 16;         // per-lane candidate list entries between flushes
+constexpr int kMaxLdsSpheres = 1024; // scenes up to this size are LDS-resident (32 B per sphere)
+
+// Relative widening of the filter: the filter accepts when hb^2 (1+k) + r^2 (1+k) >= |oc|^2 with
+// (1+k) = (1+2^-15)^2; the reference's own rounding error in its discriminant is < 2^-19 relative
+// to (|oc|^2 + r^2), so every sphere whose reference discriminant is >= 0 is
+// a candidate.
+constexpr float kFilterScale = 1.0f + 0x1p-15f;                          // applied to d-hat
+constexpr float kFilterScaleSq = (1.0f + 0x1p-15f) * (1.0f + 0x1p-15f);  // applied to r^2 (host)
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(float t, V3 v) { return {t * v.x, t * v.y, t * v.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+// Vector3.cpp:39-41 — (x x' + y y') + z z', each op rounded (TU is contract-off).
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// Vector3.cpp:35-37 and 61-63 — reciprocal then three multiplies.
+__device__ __forceinline__ V3 div_by(V3 v, float t) { return (1.0f / t) * v; }
+__device__ __forceinline__ V3 unit_vector(V3 v) { return div_by(v, __builtin_sqrtf(length_squared(v))); }
+// Vector3.cpp:65-67.
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }
+// Vector3.cpp:69-74.
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float eta) {
+    const float cos_theta = fminf(dot(-uv, n), 1.0f);
+    const V3 perp = eta * (uv + cos_theta * n);
+    const V3 par = (-__builtin_sqrtf(fabsf(1.0f - length_squared(perp)))) * n;
+    return perp + par;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11), replacing the two sequential mt19937
+// streams of MathUtils.hpp:15-25.  key = seed, counter = (pixel, sample, bounce, stream).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+// 24 random bits -> [0, 1): exactly representable, never 1.
+__device__ __forceinline__ float u01(uint32_t x) { return static_cast<float>(x >> 8) * 0x1p-24f; }
+
+// Direct maps with the same distributions as the reference's rejection samplers.
+// Uniform on the unit disk (Vector3.cpp:53-59).  v_sin/v_cos take revolutions.
+__device__ __forceinline__ void sample_disk(float u1, float u2, float& x, float& y) {
+    const float r = __builtin_sqrtf(u1);
+    x = r * __builtin_amdgcn_cosf(u2);
+    y = r * __builtin_amdgcn_sinf(u2);
+}
+// Uniform on the unit sphere: what unit_vector(random_in_unit_sphere()) produces (Vector3.cpp:49-51).
+__device__ __forceinline__ V3 sample_unit_vector(float u1, float u2) {
+    const float z = 1.0f - 2.0f * u1;
+    const float rho = __builtin_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    return {rho * __builtin_amdgcn_cosf(u2), rho * __builtin_amdgcn_sinf(u2), z};
+}
+// Uniform in the unit ball (Vector3.cpp:3-9): direction x cbrt(u).
+__device__ __forceinline__ V3 sample_in_unit_sphere(float u1, float u2, float u3) {
+    const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u3) * (1.0f / 3.0f));
+    return rad * sample_unit_vector(u1, u2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene as the kernels see it.
+// ---------------------------------------------------------------------------------------------
+struct SceneDev {
+    const float4* filt;   // [npad] cx, cy, cz, r^2 (1+k): filter operands; pads never pass
+    const float4* exact;  // [npad] cx, cy, cz, r*r  (fl(r*r), Sphere3.hpp:35)
+    const float4* mat0;   // [n] colour r, g, b, roughness
+    const float4* mat1;   // [n] metallic, ior, type (int bits), 1/radius (fl(1/r), Vector3.cpp:36)
+    int32_t n;
+    int32_t npad;         // n rounded up to a multiple of 32
+};
+
+struct CameraDev {
+    V3 origin, llc, horizontal, vertical, u, v, w;
+    float lens_radius;
+};
+
+struct Ray {
+    V3 o, d;
+};
+
+// Wave-level helpers (wave64).
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+__device__ __forceinline__ int lane_prefix(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+}
+
+// One exact ray-sphere test: Sphere3.hpp:31-49 operation for operation (TU is contract-off; `a`
+// is hoisted per ray and r*r precomputed per sphere, both bit-identical to the reference's
+// per-call values).  Comparison polarity is the reference's: every test is false for NaN.
+__device__ __forceinline__ bool sphere_root_exact(const Ray& r, float a, float4 s /*cx,cy,cz,rr*/, float t_min, float t_max,
+                                                  float& root_out) {
+    const V3 oc = r.o - V3{s.x, s.y, s.z};
+    const float half_b = dot(oc, r.d);
+    const float c = length_squared(oc) - s.w;
+    const float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return false;
+    const float sqrtd = __builtin_sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    root_out = root;
+    return true;
+}
+
+// Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
+//
+// Stage 1 (filter, all spheres, pure VALU): a conservative sign test of a widened discriminant in
+// normalised-direction form, 11 VALU instructions per sphere, every lane of the wavefront testing the
+// same sphere (operands broadcast from LDS, or from scalar/global loads when !LDS).  The sign bits
+// are funnel-shifted into one mask word per 32 spheres.
+// Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
+// Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
+// against its running `closest`; ascending order reproduces the reference's tie rule (a later
+// sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
+template <bool LDS>
+struct Intersector {
+    const float4* filt;    // LDS or global
+    const float4* exact;   // LDS or global (cx, cy, cz, r*r)
+    uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
+    int n;
+    int nwords;
+    int lane;
+
+    __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int& cnt, float& closest, int& best,
+                                          uint32_t& n_exact) const {
+        for (int k = 0; wave_any(k < cnt); ++k) {
+            if (k < cnt) {
+                const int j = list[k * kWave + lane];
+                const float4 s = exact[j];
+                float root;
+                if (sphere_root_exact(r, a, s, t_min, closest, root)) {
+                    closest = root;
+                    best = j;
+                }
+                ++n_exact;
+            }
+        }
+        cnt = 0;
+    }
+
+    __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
+                                                uint32_t& n_exact) const {
+        // Reference `a` (Sphere3.hpp:33), hoisted.
+        const float a = length_squared(r.d);
+        // Filter operands: d-hat widened by (1+2^-15).  v_rsq_f32 is 1 ulp; its error is far inside the margin.
+        const float inv_len = __builtin_amdgcn_rsqf(a) * kFilterScale;
+        const float dhx = r.d.x * inv_len, dhy = r.d.y * inv_len, dhz = r.d.z * inv_len;
+        // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
+        // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
+        const float big = 0x1p30f;
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+        const float ox = r.o.x, oy = r.o.y, oz = r.o.z;
+
+        float closest = t_max;
+        int best = -1;
+        int cnt = 0;
+        for (int w = 0; w < nwords; ++w) {
+            const float4* sp = filt + w * 32;
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float4 s = sp[i];
+                const float x = ox - s.x, y = oy - s.y, z = oz - s.z;
+                const float hb = fmaf(z, dhz, fmaf(y, dhy, x * dhx));
+                const float c = fmaf(z, z, fmaf(y, y, fmaf(x, x, -s.w)));
+                const float disc = fmaf(hb, hb, -c);
+                m = __builtin_amdgcn_alignbit(m, __float_as_uint(disc), 31);   // shift the sign bit in
+            }
+            // bit (31-i) of m is set when sphere w*32+i is certainly missed.
+            const int left = n - w * 32;                                        // uniform
+            const uint32_t valid = left >= 32 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (32 - left));
+            uint32_t cand = (safe ? ~m : 0xFFFFFFFFu) & valid;
+            if (!active) cand = 0;
+            // compaction: candidate bits -> this lane's list (ascending index); when a lane's list is
+            // full the wave runs the exact stage early and carries on
+            for (;;) {
+                while (wave_any(cand != 0 && cnt < kListCap)) {
+                    if (cand != 0 && cnt < kListCap) {
+                        const int pos = __clz(static_cast<int>(cand));
+                        cand &= ~(0x80000000u >> pos);
+                        list[cnt * kWave + lane] = static_cast<uint16_t>(w * 32 + pos);
+                        ++cnt;
+                    }
+                }
+                if (!wave_any(cand != 0)) break;
+                flush(r, a, t_min, cnt, closest, best, n_exact);
+            }
+        }
+        flush(r, a, t_min, cnt, closest, best, n_exact);
+        t_out = closest;
+        idx_out = best;
+    }
+};
+
+// hit_record construction (Sphere3.hpp:51-56, Hittable.hpp:15-18) + Material::scatter
+// (Material.cpp:6-54).  u = four uniforms in [0,1).  Returns scatter's bool; `out` is the scattered ray.
+__device__ __forceinline__ bool hit_and_scatter(const Ray& in, float t, float4 ex /*cx,cy,cz,rr*/, float4 m0, float4 m1,
+                                                const float u[4], Ray& out) {
+    const V3 center = {ex.x, ex.y, ex.z};
+    const V3 p = in.o + t * in.d;                       // Ray3.hpp:19-21
+    const V3 outward = m1.w * (p - center);             // (1/radius) * v
+    const bool front_face = dot(in.d, outward) < 0.0f;
+    const V3 normal = front_face ? outward : -outward;
+    const int type = __float_as_int(m1.z);
+    const float roughness = m0.w, metallic = m1.x, ior = m1.y;
+    if (type == 1) {                                    // Lambertian, Material.cpp:8-19
+        V3 dir = normal + roughness * sample_unit_vector(u[0], u[1]);
+        // near_zero (Vector3.cpp:138-141): the reference compares |x| promoted to double with 1e-8.
+        const double eps = 1e-8;
+        if (static_cast<double>(fabsf(dir.x)) < eps && static_cast<double>(fabsf(dir.y)) < eps &&
+            static_cast<double>(fabsf(dir.z)) < eps)
+            dir = normal;
+        out = {p, dir};
+        return true;
+    }
+    if (type == 2) {                                    // Metal, Material.cpp:20-25
+        const V3 dir = metallic * reflect(unit_vector(in.d), normal);
+        out = {p, dir + roughness * sample_in_unit_sphere(u[0], u[1], u[2])};
+        return dot(out.d, normal) > 0.0f;
+    }
+    if (type == 3) {                                    // Glass, Material.cpp:26-48
+        const float ratio = front_face ? (1.0f / ior) : ior;
+        const V3 ud = unit_vector(in.d);
+        const float cos_theta = fminf(dot(-ud, normal), 1.0f);
+        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        const bool cannot_refract = ratio * sin_theta > 1.0f;
+        float r0 = (1.0f - ratio) / (1.0f + ratio);     // Schlick, Material.cpp:28-33
+        r0 = r0 * r0;
+        const float q = 1.0f - cos_theta;
+        const float q2 = q * q;
+        const float reflectance = r0 + (1.0f - r0) * (q2 * q2 * q);
+        const V3 dir = (cannot_refract || reflectance > u[3]) ? reflect(ud, normal) : refract(ud, normal, ratio);
+        out = {p, dir};
+        return true;
+    }
+    out = {p, V3{0.0f, 0.0f, 0.0f}};                    // Type::None, Material.cpp:49-52
+    return false;
+}
+
+// main.cpp:69-71 + Camera.hpp:25-29 for pixel column x, image row from the top `row` (y = H-1-row).
+__device__ __forceinline__ Ray primary_ray(const CameraDev& cam, int x, int row, int W, int H, const float u[4]) {
+    const int y = H - 1 - row;
+    const float s = (static_cast<float>(x) + u[0]) / static_cast<float>(W - 1);
+    const float t = (static_cast<float>(y) + u[1]) / static_cast<float>(H - 1);
+    float dkx, dky;
+    sample_disk(u[2], u[3], dkx, dky);
+    const float rdx = cam.lens_radius * dkx, rdy = cam.lens_radius * dky;
+    const V3 offset = rdx * cam.u + rdy * cam.v;
+    Ray r;
+    r.o = cam.origin + offset;
+    r.d = cam.llc + s * cam.horizontal + t * cam.vertical - cam.origin - offset;
+    return r;
+}
+
+// Sky of main.cpp:98-100.
+__device__ __forceinline__ V3 sky(const V3 d) {
+    const V3 ud = unit_vector(d);
+    const float t = 0.5f * (ud.y + 1.0f);
+    return (1.0f - t) * V3{1.0f, 1.0f, 1.0f} + t * V3{0.5f, 0.7f, 1.0f};
+}
+
+} // namespace rtk

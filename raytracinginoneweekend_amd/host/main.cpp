@@ -1,0 +1,61 @@
+// Drop-in replacement of the reference executable (reference: main.cpp:20-81): same positional
+// arguments `width height spp depth`, same scene, same camera, same output file `image_binary.ppm`
+// in P6 format, same progress/timing lines on stderr — with the "Image Generation" scope executed
+// on an MI355X through librtk.so instead of the CPU loops.
+//
+// Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index.
+#include "MathUtils.hpp"
+
+#include "Camera.hpp"
+#include "Color.hpp"
+#include "HittableList.hpp"
+#include "Material.hpp"
+#include "ProfileLogScope.hpp"
+#include "Render.hpp"
+#include "Sphere3.hpp"
+
+#include <fstream>
+#include <iostream>
+#include <string>
+
+int main(int argc, char** argv) {
+    // Image (main.cpp:23-41)
+    float aspect_ratio = 3.0f / 2.0f;
+    const int image_width = argc > 1 ? static_cast<int>(std::stoll(argv[1])) : 400;
+    int image_height;
+    if (argc > 2) {
+        image_height = static_cast<int>(std::stoll(argv[2]));
+        aspect_ratio = image_width / static_cast<float>(image_height);
+    } else {
+        image_height = static_cast<int>(image_width / aspect_ratio);
+    }
+    const int samples_per_pixel = argc > 3 ? static_cast<int>(std::stoll(argv[3])) : 100;
+    const int max_depth = argc > 4 ? static_cast<int>(std::stoll(argv[4])) : 50;
+    const uint64_t seed = argc > 5 ? std::stoull(argv[5]) : 0;
+    const int device = argc > 6 ? static_cast<int>(std::stoll(argv[6])) : 0;
+
+    // World and camera (main.cpp:45-54)
+    HittableList world = random_scene();
+    Camera camera{Point3{13.0f, 2.0f, 3.0f}, Point3{0.0f, 0.0f, 0.0f}, Vector3{0.0f, 1.0f, 0.0f}, 20, aspect_ratio, 0.1f, 10.0f};
+
+    std::ofstream bin_file("image_binary.ppm", std::ios_base::binary);
+    bin_file << "P6\n" << image_width << ' ' << image_height << '\n' << 255 << '\n';
+    try {
+        rtiow::RenderResult frame;
+        {
+            PROFILE_LOG_SCOPE("Image Generation");
+            std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
+            frame = rtiow::render_image(world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device);
+            for (size_t i = 0; i < frame.rgb_sum.size(); i += 3)
+                write_color_binary(bin_file, Color{frame.rgb_sum[i], frame.rgb_sum[i + 1], frame.rgb_sum[i + 2]}, samples_per_pixel);
+            std::cerr << "\rScanlines remaining: 0 \nDone.\n";
+        }
+        std::cerr << "rays " << frame.stats.rays << "  kernel " << frame.stats.kernel_ms << " ms  "
+                  << (frame.stats.kernel_ms > 0 ? frame.stats.rays / (frame.stats.kernel_ms * 1e3) : 0.0) << " Mrays/s\n";
+    } catch (const std::exception& e) {
+        std::cerr << "\nerror: " << e.what() << '\n';
+        return 1;
+    }
+    bin_file.close();
+    return 0;
+}
