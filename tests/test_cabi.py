@@ -1,0 +1,59 @@
+"""The C-ABI library loads and exports every symbol include/rtk.h declares; argument checking and the
+no-device error path work without a GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+import raytracinginoneweekend_amd as rt
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtk_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_python_agree():
+    assert declared_symbols() == sorted(rt.C_ABI_SYMBOLS)
+
+
+def test_every_declared_symbol_is_exported():
+    lib = C.CDLL(rt.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(rt.rtk_camera) == 88
+    assert C.sizeof(rt.rtk_scene) == 8 + 11 * 8
+    assert C.sizeof(rt.rtk_params) == 48
+    assert C.sizeof(rt.rtk_stats) == 48
+
+
+def test_local_tile_count():
+    l = rt.lib()
+    # 1200 x 800 in 8 x 8 tiles = 150 x 100 = 15000 tiles
+    assert l.rtk_local_tile_count(1200, 800, 8, 8, 0, 1) == 15000
+    assert sum(l.rtk_local_tile_count(1200, 800, 8, 8, r, 8) for r in range(8)) == 15000
+    # ragged: 13 x 9 -> 2 x 2 tiles
+    assert [l.rtk_local_tile_count(13, 9, 8, 8, r, 3) for r in range(3)] == [2, 1, 1]
+    assert l.rtk_local_tile_count(13, 9, 0, 0, 0, 1) == 4          # 0,0 -> 8 x 8
+    assert l.rtk_local_tile_count(13, 9, 8, 8, 3, 3) == -1         # rank out of range
+    assert l.rtk_local_tile_count(0, 9, 8, 8, 0, 1) == -1
+
+
+def test_null_arguments_are_rejected_without_a_device():
+    l = rt.lib()
+    assert l.rtk_context_create(0, None) == -1
+    assert b"null" in l.rtk_last_error()
+    assert l.rtk_set_scene(None, None) == -1
+    assert l.rtk_synchronize(None) == -1
+
+
+@pytest.mark.skipif(rt.lib().rtk_device_count() > 0, reason="a GPU is present")
+def test_no_device_fails_loudly():
+    with pytest.raises(rt.RtkError, match="no CPU fallback"):
+        rt.Context(0)

@@ -1,0 +1,58 @@
+"""World-size-2 (and 3) CPU test of the multi-rank path with the gloo backend: tile ownership,
+padding, the single all_gather, and the de-interleave index math.  The tile CONTENT is synthetic (each
+pixel carries its own global index), so no GPU is needed; the render that fills real tiles is covered by
+tests/test_gpu_render.py::test_one_vs_n_ranks_bit_identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from np_mirror import deinterleave
+
+
+def _worker(rank, world, W, H, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import raytracinginoneweekend_amd as rt
+    from raytracinginoneweekend_amd import distributed as rd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tw = th = 8
+    tiles_x = (W + tw - 1) // tw
+    tprp = rd.tiles_per_rank_padded(W, H, world)
+    nlt = rt.local_tile_count(W, H, rank, world)
+    assert nlt <= tprp
+    local = torch.zeros((tprp, 64, 3), dtype=torch.float32)
+    # what rtk_render_tiles_device would write: local tile k is global tile k*world + rank
+    for k in range(nlt):
+        gt = k * world + rank
+        tx, ty = gt % tiles_x, gt // tiles_x
+        for j in range(64):
+            x, row = tx * tw + j % tw, ty * th + j // tw
+            if x < W and row < H:
+                p = row * W + x
+                local[k, j] = torch.tensor([p, 2 * p + 1, rank], dtype=torch.float32)
+    gathered = rd.gather_tiles(local)
+    assert tuple(gathered.shape) == (world, tprp, 64, 3)
+    img = deinterleave(gathered.numpy(), W, H, world)
+    np.save(os.path.join(out_dir, f"img{rank}.npy"), img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 40, 24), (2, 37, 23), (3, 50, 9)])
+def test_shard_gather_deinterleave(tmp_path, world, W, H):
+    port = 29000 + (os.getpid() * 7 + world * 13 + W) % 2000
+    mp.spawn(_worker, args=(world, W, H, port, str(tmp_path)), nprocs=world, join=True)
+    p = np.arange(W * H, dtype=np.float32).reshape(H, W)
+    tiles_x = (W + 7) // 8
+    rows, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    owner = ((rows // 8) * tiles_x + xs // 8) % world
+    for r in range(world):
+        img = np.load(tmp_path / f"img{r}.npy")
+        assert np.array_equal(img[..., 0], p) and np.array_equal(img[..., 1], 2 * p + 1)
+        assert np.array_equal(img[..., 2], owner)          # every pixel came from the rank that owns its tile

@@ -1,0 +1,137 @@
+"""GPU parity of the intersector through the C ABI: rtk_intersect_batch == HittableList::hit of the
+reference.  Bar: hit and index bit-exact; t bit-exact too (north_star allows 1e-5 relative; the exact
+stage reproduces the reference's operation sequence, so the test holds it to equality)."""
+import numpy as np
+import pytest
+
+from conftest import bits, load_golden
+import raytracinginoneweekend_amd as rt
+from oracle import pyoracle as po
+from test_oracle_golden import ties_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def check(got, want_hit, want_idx, want_t):
+    hit, idx, t = got
+    assert np.array_equal(hit, want_hit), "hit/miss differs in %d rays" % int((hit != want_hit).sum())
+    assert np.array_equal(idx, want_idx), "closest-sphere index differs in %d rays" % int((idx != want_idx).sum())
+    assert np.array_equal(bits(t), bits(want_t)), "t differs in %d rays" % int((bits(t) != bits(want_t)).sum())
+
+
+@pytest.mark.parametrize("batch", ["primary", "secondary", "tertiary", "random", "grazing", "inside", "degenerate"])
+def test_fixed_batches_vs_reference(gpu_ctx, batch):
+    z = load_golden("rays_stock.npz")
+    check(gpu_ctx.intersect(z[batch + "_rays"]), z[batch + "_hit"], z[batch + "_index"], z[batch + "_t"])
+
+
+def test_finite_range_vs_reference(gpu_ctx):
+    z = load_golden("rays_stock.npz")
+    check(gpu_ctx.intersect(z["primary_rays"], 0.5, 9.0), z["primary_tmin0p5_tmax9_hit"], z["primary_tmin0p5_tmax9_index"], z["primary_tmin0p5_tmax9_t"])
+
+
+def test_tie_rule_vs_reference():
+    z = load_golden("rays_ties.npz")
+    ctx = rt.Context(0)
+    ctx.set_scene(ties_scene(z))
+    check(ctx.intersect(z["rays"]), z["hit"], z["index"], z["t"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 257, 100003])
+def test_empty_and_ragged_batches(gpu_ctx, oracle_stock, n):
+    rng = np.random.default_rng(n)
+    rays = np.concatenate([rng.uniform(-13, 13, (n, 3)), rng.normal(size=(n, 3))], 1).astype(np.float32)
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.2
+    got = gpu_ctx.intersect(rays)
+    assert got[0].shape == (n,)
+    check(got, *oracle_stock.intersect(rays))
+
+
+def test_one_million_random_rays_vs_oracle(gpu_ctx, oracle_stock):
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-14, 14, (n, 3)); rays[:, 1] = rng.uniform(0.001, 3, n)
+    rays[:, 3:6] = rng.normal(size=(n, 3)) * rng.uniform(1e-3, 1e3, (n, 1))
+    # a third start ON sphere surfaces heading outward along the normal + noise (self-intersection regime of
+    # the reference's Lambertian bounce, SURVEY.md §7 hard part 3)
+    s = oracle_stock.get_scene()
+    k = rng.integers(0, 484, n // 3)
+    nrm = rng.normal(size=(n // 3, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    c = np.stack([s["cx"][k], s["cy"][k], s["cz"][k]], 1)
+    rays[: n // 3, 0:3] = c + nrm * s["radius"][k][:, None]
+    rays[: n // 3, 3:6] = nrm + rng.normal(size=(n // 3, 3)) * rng.choice([1.0, 0.1, 1e-3], (n // 3, 1))
+    check(gpu_ctx.intersect(rays), *oracle_stock.intersect(rays))
+
+
+def _odd_scene(rng, n):
+    s = {"cx": rng.uniform(-10, 10, n), "cy": rng.uniform(0, 2, n), "cz": rng.uniform(-10, 10, n), "radius": rng.uniform(0.05, 1.0, n)}
+    s = {k: v.astype(np.float32) for k, v in s.items()}
+    for k in ("mat_r", "mat_g", "mat_b", "roughness", "metallic", "ior"):
+        s[k] = np.ones(n, np.float32)
+    s["mat_type"] = np.ones(n, np.int32)
+    return s
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 1025, 3000])
+def test_scene_sizes_lds_and_global_paths(n):
+    """n <= 1024 is LDS-resident, beyond that the filter reads the sphere list from global memory."""
+    rng = np.random.default_rng(n)
+    s = _odd_scene(rng, n)
+    o = po.Oracle(); o.set_scene(s)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    m = 20000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    check(ctx.intersect(rays), *o.intersect(rays))
+    ctx.close()
+
+
+def test_unsafe_spheres_and_negative_radius():
+    """Spheres the filter cannot bound (NaN / inf / huge / tiny) are always sent to the exact stage;
+    negative radii (hollow-glass trick) behave as in the reference."""
+    rng = np.random.default_rng(3)
+    s = _odd_scene(rng, 40)
+    s["radius"][3] = -0.7
+    s["radius"][5] = np.inf
+    s["cx"][7] = np.nan
+    s["radius"][9] = 1e-30
+    s["cy"][11] = 3e38
+    s["radius"][13] = 0.0
+    s["radius"][15] = np.nan
+    s["cz"][17] = -np.inf
+    s["radius"][19] = 1e25
+    s["cx"][21] = 2e9
+    o = po.Oracle(); o.set_scene(s)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    m = 50000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    rays[::7, 0:3] = (s["cx"][9], s["cy"][9], s["cz"][9])            # from the centre of the tiny sphere
+    rays[::11, 0:3] = (s["cx"][13], s["cy"][13], s["cz"][13])        # from the centre of the zero-radius sphere
+    check(ctx.intersect(rays), *o.intersect(rays))
+    ctx.close()
+
+
+def test_large_scene_config4_vs_oracle():
+    """BASELINE.json config 4: ~10k spheres (grid widened to [-50,50)^2), global-memory filter path."""
+    s = rt.scaled_scene(k=50)
+    o = po.Oracle(); o.set_scene(s)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    rng = np.random.default_rng(9)
+    m = 30000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-50, 50, m); rays[:, 1] = rng.uniform(0.01, 4, m); rays[:, 2] = rng.uniform(-50, 50, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.2
+    check(ctx.intersect(rays), *o.intersect(rays))
+    ctx.close()
+
+
+def test_errors(gpu_ctx):
+    ctx = rt.Context(0)
+    with pytest.raises(rt.RtkError, match="rtk_set_scene first"):
+        ctx.intersect(np.zeros((4, 6), np.float32))
+    bad = _odd_scene(np.random.default_rng(0), 4)
+    bad = {k: v[:0] for k, v in bad.items()}
+    with pytest.raises(rt.RtkError, match="0 spheres"):
+        ctx.set_scene(bad)
+    ctx.close()

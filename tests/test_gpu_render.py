@@ -1,0 +1,196 @@
+"""GPU render parity through the C ABI.
+
+Image bar (BASELINE.json north_star): the 500-spp GPU image against the 2000-spp CPU
+golden of the same scene, camera and depth must reach PSNR >= 40 dB on the write_color_binary bytes,
+i.e. per-pixel 8-bit RMSE <= 2.55.  (Two independent 500-spp REFERENCE renders are themselves only
+42.5 dB apart; the expected value against a 2000-spp image is ~44.5 dB.)
+The RNG is counter-based, so parity with the reference's mt19937 streams is distributional.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, load_golden
+import raytracinginoneweekend_amd as rt
+from oracle import pyoracle as po
+from np_mirror import deinterleave
+
+pytestmark = pytest.mark.gpu
+
+PSNR_MIN_DB = 40.0
+RMSE_MAX_8BIT = 2.55
+
+
+def rmse_u8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d)))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    z = load_golden("image_120x80_2000spp.npz")
+    return z["rgb_sum"], int(z["spp"]), int(z["depth"]), float(z["segments"]) / (120 * 80 * int(z["spp"]))
+
+
+def test_image_matches_cpu_reference_at_500spp(gpu_ctx, golden):
+    gsum, gspp, depth, gseg = golden
+    W, H, spp = 120, 80, 500
+    img, st = gpu_ctx.render(rt.stock_camera(W / H), W, H, spp, depth, seed=2025)
+    a, b = po.quantise(img, spp), po.quantise(gsum, gspp)
+    psnr, rmse = po.psnr_u8(a, b), rmse_u8(a, b)
+    print("PSNR %.2f dB, 8-bit RMSE %.3f" % (psnr, rmse))
+    assert psnr >= PSNR_MIN_DB and rmse <= RMSE_MAX_8BIT
+    # no bias: mean linear radiance per channel within 0.5 %
+    assert np.allclose((img / spp).mean((0, 1)), (gsum / gspp).mean((0, 1)), rtol=5e-3)
+    # same path-length statistics (the long Lambertian self-intersection tail included, SURVEY.md §7 hard part 3)
+    assert st["samples"] == W * H * spp
+    assert abs(st["rays"] / st["samples"] - gseg) < 0.01 * gseg
+
+
+def test_bias_free_at_2000spp(gpu_ctx, golden):
+    """At equal sample counts the GPU image is as close to the CPU golden as an independent CPU render is:
+    >= 43 dB (the asymptote for 2000 vs 2000 spp is ~48 dB; a 1 % sampler bias would cap it near 40)."""
+    gsum, gspp, depth, _ = golden
+    img, _ = gpu_ctx.render(rt.stock_camera(1.5), 120, 80, 2000, depth, seed=1)
+    assert po.psnr_u8(po.quantise(img, 2000), po.quantise(gsum, gspp)) >= 43.0
+
+
+def test_deterministic_and_seeded(gpu_ctx):
+    cam = rt.stock_camera(1.5)
+    a, sa = gpu_ctx.render(cam, 96, 64, 32, 50, seed=5)
+    b, sb = gpu_ctx.render(cam, 96, 64, 32, 50, seed=5)
+    c, _ = gpu_ctx.render(cam, 96, 64, 32, 50, seed=6)
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+    assert not np.array_equal(a, c)
+
+
+def _render_sharded_np(ctx, cam, W, H, spp, depth, seed, world, tile_w=8, tile_h=8):
+    """Each 'rank' renders its tiles on this one GPU; gather = stack; de-interleave in numpy."""
+    import torch
+    tprp = rt.local_tile_count(W, H, 0, world, tile_w, tile_h)
+    parts, rays = [], 0
+    for r in range(world):
+        buf = torch.zeros((tprp, 64, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        st = ctx.render_tiles_device(cam, rt.make_params(W, H, spp, depth, seed, 0.001, r, world, tile_w, tile_h), buf.data_ptr(), True)
+        parts.append(buf.cpu().numpy())
+        rays += st["rays"]
+    return deinterleave(np.stack(parts), W, H, world, tile_w, tile_h), rays
+
+
+@pytest.mark.parametrize("W,H", [(96, 64), (37, 23)])
+def test_one_vs_n_ranks_bit_identical(gpu_ctx, W, H):
+    """Tiles interleaved over 1, 2, 3, 8 ranks, and other tile shapes, give the SAME image bits and ray
+    count as the single-device render: RNG keys use the global pixel index and accumulation is integer."""
+    cam = rt.stock_camera(W / H)
+    ref, st = gpu_ctx.render(cam, W, H, 24, 50, seed=3)
+    for world in (1, 2, 3, 8):
+        img, rays = _render_sharded_np(gpu_ctx, cam, W, H, 24, 50, 3, world)
+        assert np.array_equal(bits(img), bits(ref)), world
+        assert rays == st["rays"]
+    for tw, th in ((16, 4), (64, 1), (4, 16)):
+        img, rays = _render_sharded_np(gpu_ctx, cam, W, H, 24, 50, 3, 2, tw, th)
+        assert np.array_equal(bits(img), bits(ref)), (tw, th)
+
+
+def test_device_deinterleave_matches_numpy(gpu_ctx):
+    import torch
+    W, H, world = 37, 23, 3
+    tprp = rt.local_tile_count(W, H, 0, world)
+    g = torch.rand((world, tprp, 64, 3), dtype=torch.float32, device="cuda:0")
+    img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.deinterleave_device(g.data_ptr(), tprp, rt.make_params(W, H, 1, 1, 0, 0.001, 0, world), img.data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(img.cpu().numpy(), deinterleave(g.cpu().numpy(), W, H, world))
+
+
+def test_depth_semantics(gpu_ctx):
+    """main.cpp:87-89: depth <= 0 gathers nothing and traces nothing; depth 1 traces exactly the primary rays,
+    and only sky pixels are lit."""
+    cam = rt.stock_camera(1.5)
+    img0, st0 = gpu_ctx.render(cam, 48, 32, 4, 0)
+    assert st0["rays"] == 0 and st0["samples"] == 48 * 32 * 4 and not img0.any()
+    img1, st1 = gpu_ctx.render(cam, 48, 32, 4, 1)
+    assert st1["rays"] == st1["samples"]
+    assert img1[0].min() > 0 and not img1[-1].any()        # top row is sky, bottom row hit the ground
+    _, st50 = gpu_ctx.render(cam, 48, 32, 4, 50)
+    _, st100 = gpu_ctx.render(cam, 48, 32, 4, 100)
+    assert st1["rays"] < st50["rays"] <= st100["rays"]
+
+
+def test_sky_pixels_are_the_analytic_gradient(gpu_ctx):
+    """Rows that see only sky: the pixel mean is the reference's lerp at the pixel's mean direction."""
+    W, H, spp = 120, 80, 256
+    cam = rt.stock_camera(W / H)
+    img, _ = gpu_ctx.render(cam, W, H, spp, 50, seed=4)
+    row = 0
+    v = (H - 1 - row + 0.5) / (H - 1)
+    u = (np.arange(W) + 0.5) / (W - 1)
+    d = cam[3:6] + u[:, None] * cam[6:9] + v * cam[9:12] - cam[0:3]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = 0.5 * (d[:, 1] + 1)
+    want = (1 - t)[:, None] * np.ones(3) + t[:, None] * np.array([0.5, 0.7, 1.0])
+    assert np.allclose(img[row] / spp, want, atol=2e-3)
+
+
+def test_run_length_changes_only_rounding(gpu_ctx):
+    cam = rt.stock_camera(1.5)
+    a, sa = gpu_ctx.render(cam, 64, 48, 40, 50, seed=8, run_len=40)
+    b, sb = gpu_ctx.render(cam, 64, 48, 40, 50, seed=8, run_len=1)
+    c, sc = gpu_ctx.render(cam, 64, 48, 40, 50, seed=8, run_len=7)
+    assert sa["rays"] == sb["rays"] == sc["rays"]
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-5) and np.allclose(a, c, rtol=1e-5, atol=1e-5)
+
+
+def test_quantiser_byte_exact_vs_reference(gpu_ctx):
+    import torch
+    z = load_golden("quantise.npz")
+    sums = torch.from_numpy(z["sums"]).cuda()
+    out = torch.zeros(len(z["sums"]), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.quantise_device(sums.data_ptr(), len(z["sums"]) // 3, int(z["spp"]), out.data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), z["bytes"])
+
+
+def test_full_size_config2_properties(gpu_ctx, golden):
+    """BASELINE.json config 2 (1200 x 800, 500 spp, depth 50) at full size: size-independent properties."""
+    gsum, gspp, depth, gseg = golden
+    W, H, spp = 1200, 800, 500
+    cam = rt.stock_camera(W / H)
+    img, st = gpu_ctx.render(cam, W, H, spp, depth, seed=11)
+    assert st["samples"] == W * H * spp
+    assert abs(st["rays"] / st["samples"] - gseg) < 0.01 * gseg
+    # every sample's radiance is in [0, 1]^3 for this scene (albedos and sky <= 1)
+    assert img.min() >= 0 and img.max() <= spp * (1 + 1e-5)
+    # same mean radiance as the CPU golden (different resolution, same field of view): within 1 %
+    assert np.allclose((img / spp).mean((0, 1)), (gsum / gspp).mean((0, 1)), rtol=1e-2)
+    # box-downsampled 10x it is the golden's picture (edges are mis-registered by (W-1) vs (w-1): loose bound)
+    small = img.reshape(80, 10, 120, 10, 3).mean((1, 3))
+    assert po.psnr_u8(po.quantise(small, spp), po.quantise(gsum, gspp)) > 30.0
+    # idempotence: the same call again gives the same bits
+    img2, st2 = gpu_ctx.render(cam, W, H, spp, depth, seed=11)
+    assert np.array_equal(bits(img), bits(img2)) and st["rays"] == st2["rays"]
+
+
+def test_glass_heavy_config5_runs_and_matches_oracle_statistics():
+    """BASELINE.json config 5: 10 % diffuse / 40 % metal / 50 % glass, depth 100."""
+    s = rt.scaled_scene(k=11, diffuse_below=0.1, metal_below=0.5, seed=7)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    W, H, spp, depth = 60, 40, 64, 100
+    img, st = ctx.render(rt.stock_camera(W / H), W, H, spp, depth, seed=1)
+    o = po.Oracle(); o.set_scene(s)
+    sums, _, seg = o.render_rows(po.stock_camera(W / H), W, H, spp, depth, want_u8=False)
+    assert abs(st["rays"] / st["samples"] - seg / (W * H * spp)) < 0.03 * seg / (W * H * spp)
+    assert np.allclose((img / spp).mean((0, 1)), (sums / spp).mean((0, 1)), rtol=2e-2)
+    ctx.close()
+
+
+def test_render_argument_errors(gpu_ctx):
+    cam = rt.stock_camera(1.5)
+    with pytest.raises(rt.RtkError, match="divides by"):
+        gpu_ctx.render(cam, 1, 10, 1, 1)
+    with pytest.raises(rt.RtkError, match="64 pixels"):
+        gpu_ctx.render(cam, 16, 16, 1, 1, tile_w=8, tile_h=4)
+    with pytest.raises(rt.RtkError, match="spp"):
+        gpu_ctx.render(cam, 16, 16, 0, 1)

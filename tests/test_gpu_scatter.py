@@ -1,0 +1,155 @@
+"""GPU parity of hit-record construction and Material::scatter (rtk_scatter_batch) against vectors
+recorded from the reference, plus the counter-based RNG and the primary-ray generator."""
+import numpy as np
+import pytest
+
+from conftest import bits, load_golden
+import raytracinginoneweekend_amd as rt
+from oracle import pyoracle as po
+from np_mirror import philox4x32_10, u01, unit_vector_to_uniforms
+from test_oracle_golden import _scatter_scene, glass_draw_alignment
+
+pytestmark = pytest.mark.gpu
+
+
+def test_philox_known_answers(gpu_ctx):
+    """Random123 kat_vectors for philox4x32_10."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        seed = key[0] | (key[1] << 32)
+        got = gpu_ctx.philox(seed, np.array([ctr], np.uint32))[0]
+        assert tuple(int(x) for x in got) == want
+        assert tuple(int(x) for x in philox4x32_10(np.array([ctr], np.uint32), key)[0]) == want
+    rng = np.random.default_rng(0)
+    ctr = rng.integers(0, 2**32, (5000, 4), dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(gpu_ctx.philox(0x123456789abcdef, ctr), philox4x32_10(ctr, (0x89abcdef, 0x1234567)))
+
+
+def test_hit_record_p_and_normal_vs_reference(stock_scene_golden):
+    """Lambertian with roughness 0 scatters to exactly (p, normal): compare with Sphere3::hit's p, normal."""
+    z = load_golden("sphere_hit.npz")
+    s = dict(stock_scene_golden)
+    s["mat_type"] = np.ones(484, np.int32)
+    s["roughness"] = np.zeros(484, np.float32)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    out9 = z["out9"]
+    out = ctx.scatter(z["rays"], z["sphere"], out9[:, 6].copy(), np.full((len(out9), 4), 0.25, np.float32))
+    assert np.array_equal(bits(out[:, 0:3]), bits(out9[:, 0:3]))          # p
+    # normal + 0*unit: equal to the normal except that -0.0 + 0.0 = +0.0
+    assert np.array_equal(out[:, 3:6], out9[:, 3:6])
+    assert (out[:, 6] == 1).all()
+    ctx.close()
+
+
+def test_metal_mirror_and_absorb_vs_reference():
+    z = load_golden("scatter.npz")
+    scene, n = _scatter_scene(z, "metal")
+    ctx = rt.Context(0); ctx.set_scene(scene)
+    want = z["metal_out7"]
+    # invert the ball map so the GPU draws (nearly) the vector the reference drew
+    d = z["metal_draws"].astype(np.float64)
+    rad = np.linalg.norm(d, axis=1)
+    u1, u2 = unit_vector_to_uniforms((d / rad[:, None]).astype(np.float32))
+    u = np.stack([u1, u2, (rad ** 3).astype(np.float32), np.zeros(n, np.float32)], 1)
+    out = ctx.scatter(z["metal_rays"], np.arange(n, dtype=np.int32), z["metal_t"], u)
+    mirror = scene["roughness"] == 0
+    assert mirror.sum() > 100
+    assert np.array_equal(bits(out[mirror]), bits(want[mirror]))         # no random input: bit-exact
+    assert np.array_equal(bits(out[:, 0:3]), bits(want[:, 0:3]))         # origin p never depends on the draw
+    assert np.allclose(out[:, 3:6], want[:, 3:6], atol=3e-5)
+    # scatter's bool: equal except where dot(dir, n) is within the sampler's tolerance of 0
+    differs = out[:, 6] != want[:, 6]
+    assert differs.mean() < 0.002
+    ctx.close()
+
+
+def test_lambertian_vs_reference():
+    z = load_golden("scatter.npz")
+    scene, n = _scatter_scene(z, "lambertian")
+    ctx = rt.Context(0); ctx.set_scene(scene)
+    u1, u2 = unit_vector_to_uniforms(z["lambertian_draws"])
+    u = np.stack([u1, u2, np.zeros(n, np.float32), np.zeros(n, np.float32)], 1)
+    out = ctx.scatter(z["lambertian_rays"], np.arange(n, dtype=np.int32), z["lambertian_t"], u)
+    want = z["lambertian_out7"]
+    assert np.array_equal(bits(out[:, 0:3]), bits(want[:, 0:3]))
+    assert np.allclose(out[:, 3:6], want[:, 3:6], atol=3e-5)
+    assert (out[:, 6] == 1).all()
+    ctx.close()
+
+
+def test_glass_vs_reference():
+    """Reflect / refract / total internal reflection are bit-exact given the same decision; the decision
+    compares Schlick's reflectance (q^5 by multiplication here, std::pow in the reference) with the draw,
+    so it may differ only when the draw is within rounding of the reflectance."""
+    z = load_golden("scatter.npz")
+    scene, n = _scatter_scene(z, "glass")
+    o = po.Oracle(); o.set_scene(scene)
+    ctx = rt.Context(0); ctx.set_scene(scene)
+    sphere = np.arange(n, dtype=np.int32)
+    q, consumed = glass_draw_alignment(o, z["glass_rays"], sphere, z["glass_t"], z["glass_draws"])
+    u = np.zeros((n, 4), np.float32)
+    u[:, 3] = q[:, 6]
+    out = ctx.scatter(z["glass_rays"], sphere, z["glass_t"], u)
+    want = z["glass_out7"]
+    same = np.all(bits(out) == bits(want), axis=1)
+    assert same.mean() > 0.999
+    assert same[~consumed].all()                                          # total internal reflection: no draw at all
+    ctx.close()
+
+
+def test_sampler_distributions_vs_reference(gpu_ctx):
+    """The direct maps must have the distributions of the reference's rejection samplers: compare low-order
+    moments and marginals of GPU samples (through Metal/Lambertian scatter with a fixed normal) with the
+    reference's recorded samples."""
+    z = load_golden("samplers.npz")
+    n = 200000
+    rng = np.random.default_rng(11)
+    u = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    # one Lambertian and one Metal sphere; rays hit head-on so p and normal are fixed: dir - normal = draw
+    s = {k: np.array(v, np.float32) for k, v in dict(cx=[0, 10], cy=[0, 0], cz=[0, 0], radius=[1, 1], mat_r=[1, 1], mat_g=[1, 1], mat_b=[1, 1],
+                                                     roughness=[1, 1], metallic=[0, 0], ior=[1, 1]).items()}
+    s["mat_type"] = np.array([1, 2], np.int32)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    ray = np.tile(np.array([0, 0, 5, 0, 0, -1], np.float32), (n, 1))
+    lam = ctx.scatter(ray, np.zeros(n, np.int32), np.full(n, 4.0, np.float32), u)[:, 3:6] - np.array([0, 0, 1], np.float32)
+    ray2 = ray.copy(); ray2[:, 0] = 10
+    ball = ctx.scatter(ray2, np.ones(n, np.int32), np.full(n, 4.0, np.float32), u)[:, 3:6]   # metallic 0: dir = draw
+    ctx.close()
+    assert np.allclose(np.linalg.norm(lam, axis=1), 1.0, atol=2e-5)
+    ref_unit, ref_ball = z["unit_vector"].astype(np.float64), z["in_sphere"].astype(np.float64)
+    for got, ref, name in ((lam.astype(np.float64), ref_unit, "unit"), (ball.astype(np.float64), ref_ball, "ball")):
+        se = 4.5 / np.sqrt(len(ref))                                     # 4.5 sigma of the smaller sample, values bounded by 1
+        assert np.all(np.abs(got.mean(0) - ref.mean(0)) < se), name
+        assert np.all(np.abs((got ** 2).mean(0) - (ref ** 2).mean(0)) < se), name
+        assert abs(np.linalg.norm(got, axis=1).mean() - np.linalg.norm(ref, axis=1).mean()) < se, name
+        # radial CDF at a few radii (ball: r^3)
+        for r in (0.3, 0.6, 0.9):
+            assert abs((np.linalg.norm(got, axis=1) < r).mean() - (np.linalg.norm(ref, axis=1) < r).mean()) < se, (name, r)
+    assert (np.linalg.norm(ball, axis=1) <= 1.0 + 1e-5).all()
+
+
+def test_primary_rays_vs_camera_model(gpu_ctx):
+    """Camera::get_ray + pixel jitter as the render kernel evaluates them, against a float32 numpy
+    restatement fed with the same Philox uniforms (sin/cos of the disk map differ in the last bits)."""
+    W, H, seed = 200, 112, 99
+    cam = rt.stock_camera(W / H)
+    rng = np.random.default_rng(2)
+    xys = np.stack([rng.integers(0, W, 5000), rng.integers(0, H, 5000), rng.integers(0, 500, 5000)], 1).astype(np.int32)
+    got = gpu_ctx.primary_rays(cam, W, H, xys, seed)
+    ctr = np.zeros((5000, 4), np.uint32)
+    ctr[:, 0] = xys[:, 1] * W + xys[:, 0]; ctr[:, 1] = xys[:, 2]
+    r = philox4x32_10(ctr, (seed, 0))
+    u = [u01(r[:, i]) for i in range(4)]
+    f = np.float32
+    s = (xys[:, 0].astype(f) + u[0]) / f(W - 1)
+    t = ((H - 1 - xys[:, 1]).astype(f) + u[1]) / f(H - 1)
+    rad = np.sqrt(u[2]); ang = 2 * np.pi * u[3].astype(np.float64)
+    dx, dy = (rad * np.cos(ang)).astype(f) * cam[21], (rad * np.sin(ang)).astype(f) * cam[21]
+    off = dx[:, None] * cam[12:15] + dy[:, None] * cam[15:18]
+    o = cam[0:3] + off
+    d = cam[3:6] + s[:, None] * cam[6:9] + t[:, None] * cam[9:12] - cam[0:3] - off
+    assert np.allclose(got[:, 0:3], o, atol=1e-6) and np.allclose(got[:, 3:6], d, atol=2e-6)
+    # u, v stay inside the viewport: every primary ray of the stock camera points roughly at the origin
+    assert (got[:, 3] < 0).all()

@@ -1,0 +1,331 @@
+"""Record the golden fixtures under tests/golden/ from the REAL reference, compiled unmodified from
+/root/reference by oracle/Makefile (oracle/_ref/libref_harness.so, oracle/_ref/rtiow_ref).
+
+Run in the build container only (the reference does not exist on the GPU box):
+    make -C oracle ref && python tools/make_golden.py
+
+Fixtures are data: inputs and the reference's outputs.  Each RNG-dependent reference call runs in a
+fresh subprocess because the reference keeps its two mt19937 engines in function-local statics
+(MathUtils.hpp:17,23).
+
+Files written (all small .npz):
+  scene_stock.npz        random_scene() as the reference builds it (main.cpp:116-158)
+  camera_stock.npz       Camera fields for three aspect ratios (Camera.hpp:8-23)
+  rays_stock.npz         fixed ray batches vs HittableList::hit on the stock scene (hit, index, t)
+  rays_ties.npz          a small scene with duplicated / concentric / touching spheres (tie rule)
+  sphere_hit.npz         Sphere3::hit per (ray, sphere): p, normal, t, front_face
+  scatter.npz            Material::scatter per branch, with the draws the reference consumed
+  samplers.npz           first outputs of the reference samplers (RNG plumbing)
+  quantise.npz           write_color_binary known answers
+  ppm_hashes.json        SHA-256 of image_binary.ppm for three argv sets (re-derived here)
+  image_120x80_2000spp.npz   high-spp linear golden image from the oracle (pinned by the hashes above)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "rtiow_ref")
+
+fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+up = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+FIELDS = ("cx", "cy", "cz", "radius", "mat_r", "mat_g", "mat_b", "roughness", "metallic", "ior", "mat_type")
+
+
+def harness():
+    h = C.CDLL(HARNESS)
+    h.ref_random_scene.argtypes = [fp] * 10 + [ip]
+    h.ref_camera.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+    h.ref_list_hit.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_uint64, C.c_float, C.c_float, up, ip, fp]
+    h.ref_sphere_hit.argtypes = [fp, fp, fp, C.c_uint64, C.c_float, C.c_float, fp]
+    h.ref_sample.argtypes = [C.c_int, C.c_uint64, fp]
+    h.ref_hit_and_scatter.argtypes = [fp, fp, fp, fp, C.c_uint64, C.c_float, C.c_float, fp, fp]
+    h.ref_write_color_binary.argtypes = [fp, C.c_uint64, C.c_int, up]
+    return h
+
+
+# ---- tasks that need a fresh process --------------------------------------------------------------
+
+def _task_scene(_):
+    h = harness()
+    arrs = [np.zeros(1024, np.float32) for _ in range(10)] + [np.zeros(1024, np.int32)]
+    n = h.ref_random_scene(*arrs)
+    return {k: a[:n].copy() for k, a in zip(FIELDS, arrs)}
+
+
+def _task_sample(args):
+    kind, n = args
+    h = harness()
+    out = np.zeros((n, 3) if kind != 3 else (n,), np.float32)
+    h.ref_sample(kind, n, out.reshape(-1))
+    return out
+
+
+def _task_scatter(args):
+    centers, radius, mat7, rays, t_min, t_max = args
+    h = harness()
+    n = rays.shape[0]
+    t = np.zeros(n, np.float32)
+    out = np.zeros((n, 7), np.float32)
+    h.ref_hit_and_scatter(centers, radius, mat7, rays, n, t_min, t_max, t, out)
+    return t, out
+
+
+def fresh(fn, arg=None):
+    with mp.get_context("spawn").Pool(1) as pool:
+        return pool.apply(fn, (arg,))
+
+
+# ---- helpers ----------------------------------------------------------------------------------------
+
+def ref_list_hit(h, scene, rays, t_min=0.001, t_max=np.inf):
+    rays = np.ascontiguousarray(rays, np.float32)
+    n = rays.shape[0]
+    hit = np.zeros(n, np.uint8)
+    idx = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    h.ref_list_hit(len(scene["cx"]), scene["cx"], scene["cy"], scene["cz"], scene["radius"], rays, n, t_min, t_max, hit, idx, t)
+    return hit, idx, t
+
+
+def tangent_rays(rng, scene, n, rel_eps):
+    """Rays aimed at the silhouette of a random sphere, offset by rel_eps * radius either side."""
+    k = rng.integers(0, len(scene["cx"]), n)
+    c = np.stack([scene["cx"][k], scene["cy"][k], scene["cz"][k]], 1).astype(np.float64)
+    r = scene["radius"][k].astype(np.float64)
+    o = np.stack([rng.uniform(-14, 14, n), rng.uniform(0.05, 4, n), rng.uniform(-14, 14, n)], 1)
+    oc = c - o
+    dist = np.linalg.norm(oc, axis=1)
+    ok = dist > r * 1.5
+    w = oc / dist[:, None]
+    a = rng.normal(size=(n, 3))
+    a -= (a * w).sum(1, keepdims=True) * w
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    # tangent direction: angle theta with sin(theta) = r/dist
+    s = np.clip(r * (1.0 + rel_eps * rng.choice([-1.0, 0.0, 1.0], n)) / dist, 0, 0.999)
+    d = w * np.sqrt(1 - s * s)[:, None] + a * s[:, None]
+    d *= rng.uniform(0.05, 8.0, (n, 1))          # unnormalised on purpose
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    return rays[ok]
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    if not os.path.exists(HARNESS):
+        raise SystemExit("build the reference first: make -C oracle ref")
+    h = harness()
+    from oracle import pyoracle as po
+
+    # 1. stock scene, from the reference's own random_scene()
+    scene = fresh(_task_scene)
+    np.savez_compressed(os.path.join(GOLD, "scene_stock.npz"), **scene)
+    print("scene", len(scene["cx"]), np.bincount(scene["mat_type"]))
+
+    # 2. camera fields
+    cams = {}
+    for name, aspect in (("a1p5", 1.5), ("a400_225", float(np.float32(400) / np.float32(225))), ("a16_9", float(np.float32(3840) / np.float32(2160)))):
+        out = np.zeros(22, np.float32)
+        h.ref_camera(np.array([13, 2, 3], np.float32), np.zeros(3, np.float32), np.array([0, 1, 0], np.float32), 20.0, aspect, 0.1, 10.0, out)
+        cams[name] = out
+        cams[name + "_aspect"] = np.float32(aspect)
+    np.savez_compressed(os.path.join(GOLD, "camera_stock.npz"), **cams)
+
+    # 3. ray batches on the stock scene
+    rng = np.random.default_rng(20251111)
+    o = po.Oracle()
+    o.set_scene(scene)
+    batches = {}
+    # primary rays as Camera::get_ray makes them (lens offsets from a numpy disk sampler)
+    W, H = 200, 112
+    cam = cams["a1p5"]
+    org, llc, hor, ver, cu, cv = cam[0:3], cam[3:6], cam[6:9], cam[9:12], cam[12:15], cam[15:18]
+    n = 6000
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    rad = np.sqrt(rng.uniform(0, 1, n)) * cam[21]
+    off = (rad * np.cos(ang))[:, None] * cu + (rad * np.sin(ang))[:, None] * cv
+    prim = np.concatenate([org + off, llc + s[:, None] * hor + t[:, None] * ver - org - off], 1).astype(np.float32)
+    batches["primary"] = prim
+    # secondary rays: scatter the primary hits with random unit vectors through the oracle
+    hit, idx, tt = ref_list_hit(h, scene, prim)
+    sel = np.nonzero(hit)[0]
+    rnd7 = np.zeros((len(sel), 7), np.float32)
+    v = rng.normal(size=(len(sel), 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    rnd7[:, 0:3] = v
+    rnd7[:, 3:6] = v * np.cbrt(rng.uniform(0, 1, (len(sel), 1)))
+    rnd7[:, 6] = rng.uniform(0, 1, len(sel))
+    sc = o.scatter(prim[sel], idx[sel], tt[sel], rnd7)
+    sec = sc[sc[:, 6] > 0][:, 0:6]
+    batches["secondary"] = np.ascontiguousarray(sec, np.float32)
+    # third generation, from inside glass and off the ground at grazing angles
+    hit2, idx2, tt2 = ref_list_hit(h, scene, batches["secondary"])
+    sel2 = np.nonzero(hit2)[0]
+    rnd7b = np.zeros((len(sel2), 7), np.float32)
+    v = rng.normal(size=(len(sel2), 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    rnd7b[:, 0:3] = v; rnd7b[:, 3:6] = v * 0.5; rnd7b[:, 6] = rng.uniform(0, 1, len(sel2))
+    sc2 = o.scatter(batches["secondary"][sel2], idx2[sel2], tt2[sel2], rnd7b)
+    batches["tertiary"] = np.ascontiguousarray(sc2[sc2[:, 6] > 0][:, 0:6], np.float32)
+    # random rays
+    n = 6000
+    rr = np.zeros((n, 6), np.float32)
+    rr[:, 0] = rng.uniform(-14, 14, n); rr[:, 1] = rng.uniform(0.0, 3.0, n); rr[:, 2] = rng.uniform(-14, 14, n)
+    rr[:, 3:6] = rng.normal(size=(n, 3)) * rng.uniform(0.01, 20.0, (n, 1))
+    batches["random"] = rr
+    # grazing rays at several distances from the silhouette
+    batches["grazing"] = np.concatenate([tangent_rays(rng, scene, 3000, e) for e in (0.0, 1e-7, 1e-6, 1e-5, 1e-3)])
+    # origins inside spheres (incl. the big glass sphere) and exactly on surfaces
+    n = 2000
+    k = rng.integers(0, len(scene["cx"]), n)
+    k[:200] = 481
+    c = np.stack([scene["cx"][k], scene["cy"][k], scene["cz"][k]], 1)
+    inside = np.zeros((n, 6), np.float32)
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    inside[:, 0:3] = c + dirs * (scene["radius"][k] * rng.choice([0.0, 0.5, 0.999, 1.0], n))[:, None]
+    inside[:, 3:6] = rng.normal(size=(n, 3))
+    batches["inside"] = inside
+    # degenerate rays: zero direction, NaN, inf, huge, denormal
+    deg = []
+    base_o = [(13, 2, 3), (0, 1, 0), (0, 0.2, 0), (4, 1, 0), (-4, 3, 0.5)]
+    nan, inf = np.nan, np.inf
+    bad_d = [(0, 0, 0), (nan, 0, -1), (0, nan, 0), (inf, 0, 0), (-inf, -inf, 1), (1e-30, -1e-30, 1e-30), (1e-42, 0, -1e-42),
+             (1e19, -1e19, 1e19), (3e38, 0, 0), (0, -0.0, 0), (1e-20, -1, 1e-20), (0, -1, 0), (0, 1, 0)]
+    for bo in base_o:
+        for bd in bad_d:
+            deg.append(bo + bd)
+    bad_o = [(nan, 2, 3), (inf, 2, 3), (1e30, 2, 3), (13, -inf, 3), (1e12, 1e12, 1e12), (2e9, 1, 0), (-1e38, 1e38, 0)]
+    for bo in bad_o:
+        for bd in [(-13, -2, -3), (0, -1, 0), (1, 1, 1), (nan, nan, nan)]:
+            deg.append(bo + bd)
+    batches["degenerate"] = np.array(deg, np.float32)
+    expect = {}
+    for name, rays in batches.items():
+        hit, idx, t = ref_list_hit(h, scene, rays)
+        expect[name + "_rays"] = rays
+        expect[name + "_hit"] = hit
+        expect[name + "_index"] = idx
+        expect[name + "_t"] = t
+        print("batch", name, rays.shape[0], "hits", int(hit.sum()))
+    # the same primary batch under a finite t_max and a different t_min
+    hit, idx, t = ref_list_hit(h, scene, batches["primary"], 0.5, 9.0)
+    expect["primary_tmin0p5_tmax9_hit"], expect["primary_tmin0p5_tmax9_index"], expect["primary_tmin0p5_tmax9_t"] = hit, idx, t
+    np.savez_compressed(os.path.join(GOLD, "rays_stock.npz"), **expect)
+
+    # 4. tie rule: duplicated / concentric / touching spheres, list order matters
+    ts = {
+        "cx": np.array([0, 0, 0, 2, 2, 0, 5, 5, 5, 0], np.float32),
+        "cy": np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, -100.5], np.float32),
+        "cz": np.array([-3, -3, -3, -3, -3, -6, -3, -3, -3, -3], np.float32),
+        "radius": np.array([1, 1, 0.5, 1, 1, 1, 1, 0.25, 1, 100], np.float32),
+    }
+    n = 4000
+    tr = np.zeros((n, 6), np.float32)
+    tr[:, 0:3] = rng.uniform(-0.5, 0.5, (n, 3))
+    tgt = np.stack([rng.choice([0, 2, 5, 0], n) + rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), rng.choice([-3, -6], n) + rng.uniform(-1, 1, n)], 1)
+    tr[:, 3:6] = (tgt - tr[:, 0:3]) * rng.uniform(0.1, 3, (n, 1))
+    tr[:400, 0:3] = 0; tr[:400, 3:6] = (0, 0, -1)       # axis rays: exact ties between spheres 0 and 1
+    tr[400:800, 0:3] = (2, 0, 0); tr[400:800, 3:6] = (0, 0, -2)
+    tr[800:1000, 0:3] = (5, 0, -3)                       # from the common centre of 6, 7, 8
+    hit, idx, t = ref_list_hit(h, ts, tr)
+    print("ties", int(hit.sum()), np.bincount(idx[idx >= 0], minlength=10))
+    np.savez_compressed(os.path.join(GOLD, "rays_ties.npz"), rays=tr, hit=hit, index=idx, t=t, **ts)
+
+    # 5. Sphere3::hit per (ray, sphere)
+    allr = np.concatenate([batches["primary"][:1500], batches["secondary"][:1500], batches["grazing"][:1500], batches["inside"][:800]])
+    hit, idx, t = ref_list_hit(h, scene, allr)
+    keep = idx >= 0
+    rays_sh = np.ascontiguousarray(allr[keep]); ksh = idx[keep]
+    centers = np.ascontiguousarray(np.stack([scene["cx"][ksh], scene["cy"][ksh], scene["cz"][ksh]], 1), np.float32)
+    radius = np.ascontiguousarray(scene["radius"][ksh], np.float32)
+    out9 = np.zeros((len(ksh), 9), np.float32)
+    h.ref_sphere_hit(centers, radius, rays_sh, len(ksh), 0.001, np.inf, out9)
+    np.savez_compressed(os.path.join(GOLD, "sphere_hit.npz"), rays=rays_sh, sphere=ksh.astype(np.int32), out9=out9)
+    print("sphere_hit", len(ksh))
+
+    # 6. scatter per branch; the draws the reference consumed are recorded in a twin fresh process
+    sc_out = {}
+    nS = 3000
+    src = np.concatenate([batches["primary"], batches["secondary"], batches["inside"]])
+    hit, idx, t = ref_list_hit(h, scene, src)
+    cand = np.nonzero(hit)[0]
+    for name, mtype, kind in (("lambertian", 1, 1), ("metal", 2, 0), ("glass", 3, 3)):
+        pick = cand[rng.permutation(len(cand))[:nS]]
+        rays_m = np.ascontiguousarray(src[pick]); km = idx[pick]
+        centers = np.ascontiguousarray(np.stack([scene["cx"][km], scene["cy"][km], scene["cz"][km]], 1), np.float32)
+        radius = np.ascontiguousarray(scene["radius"][km], np.float32)
+        mat7 = np.zeros((len(km), 7), np.float32)
+        mat7[:, 0:3] = rng.uniform(0, 1, (len(km), 3))
+        mat7[:, 3] = rng.choice([0.0, 0.25, 0.5, 1.0, 3.0], len(km))     # roughness (3.0 exercises the clamp)
+        mat7[:, 4] = rng.choice([1.0, 0.5], len(km)) if mtype == 2 else 0.0
+        mat7[:, 5] = rng.choice([1.5, 1.33, 2.4, 1.0 / 1.5], len(km))
+        mat7[:, 6] = mtype
+        tt, out7 = fresh(_task_scatter, (centers, radius, mat7, rays_m, 0.001, np.inf))
+        assert (out7[:, 6] >= 0).all()
+        # glass consumes a draw only when refraction is possible; record generously and align in the test
+        draws = fresh(_task_sample, (kind, len(km)))
+        sc_out[name + "_rays"] = rays_m; sc_out[name + "_centers"] = centers; sc_out[name + "_radius"] = radius
+        sc_out[name + "_mat7"] = mat7; sc_out[name + "_t"] = tt; sc_out[name + "_out7"] = out7; sc_out[name + "_draws"] = draws
+        print("scatter", name, len(km), "returned true", int(out7[:, 6].sum()))
+    np.savez_compressed(os.path.join(GOLD, "scatter.npz"), **sc_out)
+
+    # 7. sampler outputs (first 4096 of each, each from a fresh process)
+    np.savez_compressed(os.path.join(GOLD, "samplers.npz"), in_sphere=fresh(_task_sample, (0, 4096)), unit_vector=fresh(_task_sample, (1, 4096)),
+                        in_disk=fresh(_task_sample, (2, 4096)), random_float=fresh(_task_sample, (3, 4096)))
+
+    # 8. quantiser known answers
+    sums = np.concatenate([rng.uniform(0, 120, 30000), [0, 100, 99.99999, 100.00001, 1e-30, -1, 1e9, 25, 50, 0.38, 0.39]]).astype(np.float32)
+    sums = np.resize(sums, (len(sums) // 3) * 3)
+    out = np.zeros(len(sums), np.uint8)
+    h.ref_write_color_binary(sums, len(sums) // 3, 100, out)
+    np.savez_compressed(os.path.join(GOLD, "quantise.npz"), sums=sums, spp=np.int32(100), bytes=out)
+
+    # 9. PPM hashes of the reference executable
+    hashes = {}
+    for argv in (["64"], ["200", "112", "4", "50"], ["400", "225", "10", "50"]):
+        with tempfile.TemporaryDirectory() as td:
+            subprocess.run([REF_BIN, *argv], cwd=td, check=True, stderr=subprocess.DEVNULL)
+            hashes[" ".join(argv)] = hashlib.sha256(open(os.path.join(td, "image_binary.ppm"), "rb").read()).hexdigest()
+        print(argv, hashes[" ".join(argv)])
+    json.dump(hashes, open(os.path.join(GOLD, "ppm_hashes.json"), "w"), indent=1)
+
+
+def _golden_part(args):
+    part, W, H, spp, depth = args
+    from oracle import pyoracle as po
+    o = po.Oracle()
+    o.random_scene()
+    # decorrelate the streams of the parts: skip far ahead on both engines (harness property)
+    o.discard(part * 400_000_000, part * 400_000_000 + 7)
+    sums, _, seg = o.render_rows(po.stock_camera(W / H), W, H, spp, depth, want_u8=False)
+    return sums.astype(np.float64), seg
+
+
+def golden_image(W=120, H=80, parts=8, spp_part=250, depth=50):
+    with mp.get_context("spawn").Pool(min(parts, 8)) as pool:
+        res = pool.map(_golden_part, [(p, W, H, spp_part, depth) for p in range(parts)])
+    total = sum(r[0] for r in res)
+    segs = sum(r[1] for r in res)
+    spp = parts * spp_part
+    np.savez_compressed(os.path.join(GOLD, f"image_{W}x{H}_{spp}spp.npz"), rgb_sum=total.astype(np.float32), spp=np.int32(spp), depth=np.int32(depth),
+                        segments=np.int64(segs), first_part_sum=res[0][0].astype(np.float32), spp_part=np.int32(spp_part))
+    print("golden image", W, H, spp, "segments/sample %.4f" % (segs / (W * H * spp)))
+
+
+if __name__ == "__main__":
+    if "--image-only" not in sys.argv:
+        main()
+    if "--no-image" not in sys.argv:
+        golden_image()
