@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on N MI355X of one node.
+
+Metric (BASELINE.json): Mrays/s, whole job, final random-spheres scene at 1200 x 800, 500 spp, depth 50
+(configs[1]); a "ray" is one ray segment = one call of HittableList::hit (main.cpp:90), counted by the
+kernel itself.  A "step" renders one frame of that configuration: every rank renders its interleaved
+8 x 8-pixel tiles (scene and camera already resident in HBM), the tile buffers are gathered with one
+all_gather over RCCL and de-interleaved to scanline order on every rank.  Total work is fixed as N grows
+(strong scaling: the image is sharded, BASELINE.json north_star).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
+  roofline     : the render kernel against the FP32 vector peak, algorithmic flops = 17 per ray-sphere
+                 test x 484 spheres per ray, kernel time from HIP events on the kernel's stream
+  cpu_baseline : the reference compiled unmodified (oracle/_ref/rtiow_ref, kind "reference") or, if that
+                 binary is absent, the oracle restatement (kind "port"), one thread, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracinginoneweekend_amd as rt  # noqa: E402
+from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
+
+W, H, SPP, DEPTH = 1200, 800, 500, 50
+FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
+
+
+def cpu_baseline():
+    """Single-thread CPU time of the same scene/camera/depth on a bounded sample of the workload."""
+    from oracle import pyoracle as po   # the only place bench.py touches oracle/: the baseline leg
+    ref_bin = po.REF_BINARY_PATH
+    cores = 1
+    try:
+        if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
+            # the reference executable renders whole images only: same scene, camera aspect (3:2) and depth,
+            # reduced resolution and spp; its own ProfileLogScope times the "Image Generation" scope (main.cpp:63)
+            argv = ["300", "200", "6", str(DEPTH)]
+            with tempfile.TemporaryDirectory() as td:
+                r = subprocess.run([ref_bin, *argv], cwd=td, capture_output=True, text=True, timeout=600)
+            m = re.search(r"Image Generation took ([0-9.eE+-]+) seconds", r.stderr)
+            secs = float(m.group(1))
+            # rays of that exact run: the oracle renders the bit-identical image (golden hashes), so its count is the reference's
+            o = po.Oracle()
+            o.random_scene()
+            _, _, seg = o.render_rows(po.stock_camera(1.5), 300, 200, 6, DEPTH, want_u8=False)
+            return {"value": seg / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                    "sample": "reference executable (g++ -O2 -ffp-contract=off, unmodified sources), stock scene, 300x200, 6 spp, depth 50: "
+                              "%d rays in %.2f s (its own 'Image Generation' scope)" % (seg, secs),
+                    "samples_per_s": 300 * 200 * 6 / secs}
+    except Exception as e:   # fall through to the port
+        print("cpu_baseline: reference binary failed (%s); timing the oracle port instead" % e, file=sys.stderr)
+    o = po.Oracle()
+    o.random_scene()
+    rows = (400, 404)
+    t0 = time.perf_counter()
+    _, _, seg = o.render_rows(po.stock_camera(W / H), W, H, SPP, DEPTH, rows[0], rows[1], want_u8=False)
+    secs = time.perf_counter() - t0
+    return {"value": seg / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "oracle/cpu_ref.cpp (-O2 -ffp-contract=off), rows %d-%d of the 1200x800 500-spp frame: %d rays in %.2f s" % (rows[0], rows[1] - 1, seg, secs),
+            "samples_per_s": (rows[1] - rows[0]) * W * SPP / secs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    ctx = rt.Context(local_rank)
+    scene = rt.stock_scene()
+    ctx.set_scene(scene)
+    cam = rt.stock_camera(float(np.float32(args.width) / np.float32(args.height)))
+    sr = ShardedRenderer(ctx, args.width, args.height, rank, world, device)
+
+    def step(i):
+        sr.render(cam, args.spp, args.depth, seed=i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    fence()
+    ctx.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = ctx.get_stats()
+
+    tot = torch.tensor([float(st["rays"]), float(st["samples"]), float(st["kernel_ms"]), float(st["frames_timed"]), float(st["lane_slots"]),
+                        float(st["exact_tests"])], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed, st["kernel_ms"] / max(1, st["frames_timed"])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays, samples, _, _, lane_slots, exact = (float(x) for x in tot.tolist())
+    elapsed_max, kernel_ms_max = (float(x) for x in tmax.tolist())
+
+    if rank == 0:
+        n_spheres = len(scene["cx"])
+        mrays = rays / elapsed_max / 1e6
+        # roofline of the dominant kernel (render_kernel), on rank 0's own launches
+        k_rays = st["rays"] / max(1, st["frames"])                       # rays one launch traces on this rank
+        k_ms = st["kernel_ms"] / max(1, st["frames_timed"])
+        achieved = k_rays * n_spheres * FLOP_PER_TEST / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (whole node), final scene 1200x800 500spp",
+            "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: book-1 final random-spheres scene (484 spheres, libstdc++ default-seeded), "
+                                   f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}, stock camera",
+                       "sharding": f"8x8-pixel tiles interleaved over {world} rank(s), one all_gather of fp32 tile sums per frame",
+                       "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+                         "traffic": traffic, "kernel": "render_kernel<true>", "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                         "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays,
+                         "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,8 +92,10 @@ typedef struct rtk_stats {
     uint64_t sphere_tests;     /* rays x scene size: the filter tests every sphere for every segment */
     uint64_t exact_tests;      /* candidates re-tested with the reference's exact arithmetic */
     uint64_t lane_slots;       /* 64 x wavefront passes through the intersection loop */
-    float kernel_ms;           /* HIP-event time of the render kernel alone */
-    float total_ms;            /* clear + render + finalise (+ copy-out for host outputs) */
+    float kernel_ms;           /* HIP-event time of the render kernel alone, summed over `frames_timed` frames */
+    float total_ms;            /* clear + render + finalise of the last frame (only from a call given `stats`) */
+    uint32_t frames;           /* frames rendered since the last rtk_reset_stats */
+    uint32_t frames_timed;     /* frames whose kernel time is in kernel_ms (at most 256 are kept) */
 } rtk_stats;
 
 typedef struct rtk_context rtk_context;
@@ -128,6 +130,12 @@ int64_t rtk_local_tile_count(int32_t width, int32_t height, int32_t tile_w, int3
  * outside the image are written as 0.  `stats` may be NULL; when given, the call synchronises. */
 int rtk_render_tiles_device(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
                             rtk_stats* stats);
+
+/* Counters accumulate over frames rendered with stats == NULL.  rtk_reset_stats zeroes them (asynchronous);
+ * rtk_get_stats synchronises the stream and reads them, with the render kernel's HIP-event time summed
+ * over the frames since the reset.  (A render call that is GIVEN a stats pointer resets, renders, reads.) */
+int rtk_reset_stats(rtk_context* ctx);
+int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
 
 /* Scatter gathered tile buffers back to scanline order (row 0 = top image row, i.e. y = H-1, the
  * order main.cpp:64 emits): `d_gathered` is [world_size][tiles_per_rank_padded][64][3] floats in

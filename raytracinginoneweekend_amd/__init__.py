@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = (
     "rtk_device_count", "rtk_last_error", "rtk_context_create", "rtk_context_destroy", "rtk_context_set_stream",
     "rtk_set_scene", "rtk_local_tile_count", "rtk_render_tiles_device", "rtk_deinterleave_device", "rtk_render",
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
-    "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize",
+    "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
 )
 
 
@@ -47,7 +47,8 @@ class rtk_params(C.Structure):
 
 class rtk_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("sphere_tests", C.c_uint64), ("exact_tests", C.c_uint64),
-                ("lane_slots", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+                ("lane_slots", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("frames", C.c_uint32),
+                ("frames_timed", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -64,6 +65,14 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RtkError(f"{LIB_PATH} is missing: build it with `python -m raytracinginoneweekend_amd.build` "
                            "(there is no CPU fallback)")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  If torch
+        # is going to be used in this process (bench.py, tests) it must be loaded BEFORE librtk.so so that the
+        # dynamic loader resolves librtk's libamdhip64.so.7 to the copy torch already mapped; the other order
+        # leaves torch without devices ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
         l.rtk_device_count.restype = C.c_int
@@ -85,6 +94,8 @@ def lib() -> C.CDLL:
         l.rtk_primary_rays.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, sz, vp]
         l.rtk_philox_batch.argtypes = [vp, u64, vp, sz, vp]
         l.rtk_synchronize.argtypes = [vp]
+        l.rtk_reset_stats.argtypes = [vp]
+        l.rtk_get_stats.argtypes = [vp, C.POINTER(rtk_stats)]
         _lib = l
     return _lib
 
@@ -197,6 +208,14 @@ class Context:
         s.mat_type = arrs["mat_type"].ctypes.data_as(C.POINTER(C.c_int32))
         _check(self._l.rtk_set_scene(self._h, C.byref(s)), "rtk_set_scene")
         self.n = s.n
+
+    def reset_stats(self) -> None:
+        _check(self._l.rtk_reset_stats(self._h), "rtk_reset_stats")
+
+    def get_stats(self) -> dict:
+        st = rtk_stats()
+        _check(self._l.rtk_get_stats(self._h, C.byref(st)), "rtk_get_stats")
+        return st.as_dict()
 
     def synchronize(self) -> None:
         _check(self._l.rtk_synchronize(self._h), "rtk_synchronize")

@@ -338,7 +338,10 @@ struct rtk_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev0 = nullptr, ev3 = nullptr;
+    static constexpr int kEventPairs = 256;          // render-kernel brackets of the frames since rtk_reset_stats
+    hipEvent_t kev[2 * kEventPairs] = {};
+    int n_frames = 0;                                // frames since the last reset
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};   // [LDS]
     SceneDev scene = {};
@@ -384,9 +387,8 @@ int rtk_context_create(int device, rtk_context** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreate(&c->ev2));
     HIP_TRY(hipEventCreate(&c->ev3));
+    for (hipEvent_t& e : c->kev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(c->control.reserve(512));
     HIP_TRY(hipMemset(c->control.p, 0, 512));
     *out = c;
@@ -401,9 +403,9 @@ void rtk_context_destroy(rtk_context* c) {
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
+    for (hipEvent_t e : c->kev)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -536,7 +538,10 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
         HIP_TRY(hipMemsetAsync(c->accum.p, 0, c->accum.cap, c->stream));
         c->accum_zeroed = c->accum.cap / 8;
     }
-    HIP_TRY(hipMemsetAsync(c->control.p, 0, 512, c->stream));
+    if (stats) {
+        if (int e = rtk_reset_stats(c)) return e;
+    }
+    HIP_TRY(hipMemsetAsync(c->control.p, 0, 256, c->stream));   // the packet queue; the counters behind it accumulate
 
     RenderArgs A;
     A.scene = c->scene;
@@ -559,29 +564,55 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    const int slot = c->n_frames % rtk_context::kEventPairs;
+    HIP_TRY(hipEventRecord(c->kev[2 * slot], c->stream));
     if (lds)
         hipLaunchKernelGGL(render_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
     else
         hipLaunchKernelGGL(render_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev2, c->stream));
+    HIP_TRY(hipEventRecord(c->kev[2 * slot + 1], c->stream));
+    ++c->n_frames;
     const unsigned fb = static_cast<unsigned>((n_acc + 255) / 256);
     hipLaunchKernelGGL(finalize_kernel, dim3(fb), dim3(256), 0, c->stream, static_cast<unsigned long long*>(c->accum.p), d_tile_sums, n_acc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev3, c->stream));
     if (stats) {
-        unsigned long long h[4];
-        HIP_TRY(hipMemcpyAsync(h, A.stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        stats->rays = h[0];
-        stats->samples = h[1];
-        stats->sphere_tests = h[0] * static_cast<uint64_t>(c->scene.n);
-        stats->exact_tests = h[2];
-        stats->lane_slots = h[3] * kWave;
-        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, c->ev1, c->ev2));
+        if (int e = rtk_get_stats(c, stats)) return e;
         HIP_TRY(hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
     }
+    return RTK_OK;
+}
+
+int rtk_reset_stats(rtk_context* c) {
+    if (!c) return fail(RTK_ERR_BAD_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(c->control.p) + 256, 0, 256, c->stream));
+    c->n_frames = 0;
+    return RTK_OK;
+}
+
+int rtk_get_stats(rtk_context* c, rtk_stats* stats) {
+    if (!c || !stats) return fail(RTK_ERR_BAD_ARG, "rtk_get_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, static_cast<char*>(c->control.p) + 256, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    stats->rays = h[0];
+    stats->samples = h[1];
+    stats->sphere_tests = h[0] * static_cast<uint64_t>(c->scene.n);
+    stats->exact_tests = h[2];
+    stats->lane_slots = h[3] * kWave;
+    stats->frames = static_cast<uint32_t>(c->n_frames);
+    stats->kernel_ms = 0.0f;
+    stats->total_ms = 0.0f;
+    const int timed = c->n_frames < rtk_context::kEventPairs ? c->n_frames : rtk_context::kEventPairs;
+    for (int i = 0; i < timed; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
+        stats->kernel_ms += ms;
+    }
+    stats->frames_timed = static_cast<uint32_t>(timed);
     return RTK_OK;
 }
 

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first: its bundled HIP runtime must be the one librtk.so binds to (one runtime per process)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(rt.rtk_camera) == 88
     assert C.sizeof(rt.rtk_scene) == 8 + 11 * 8
     assert C.sizeof(rt.rtk_params) == 48
-    assert C.sizeof(rt.rtk_stats) == 48
+    assert C.sizeof(rt.rtk_stats) == 56
 
 
 def test_local_tile_count():

@@ -16,7 +16,11 @@ def check(got, want_hit, want_idx, want_t):
     hit, idx, t = got
     assert np.array_equal(hit, want_hit), "hit/miss differs in %d rays" % int((hit != want_hit).sum())
     assert np.array_equal(idx, want_idx), "closest-sphere index differs in %d rays" % int((idx != want_idx).sum())
-    assert np.array_equal(bits(t), bits(want_t)), "t differs in %d rays" % int((bits(t) != bits(want_t)).sum())
+    # t: bit-equal, except that a NaN root (degenerate rays; accepted as a hit by the reference's comparison
+    # polarity) may carry a different sign/payload: x86 SSE and gfx950 generate different default NaNs.
+    nan = np.isnan(want_t)
+    assert np.array_equal(np.isnan(t), nan), "NaN roots differ"
+    assert np.array_equal(bits(t)[~nan], bits(want_t)[~nan]), "t differs in %d rays" % int((bits(t)[~nan] != bits(want_t)[~nan]).sum())
 
 
 @pytest.mark.parametrize("batch", ["primary", "secondary", "tertiary", "random", "grazing", "inside", "degenerate"])
