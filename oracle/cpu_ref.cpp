@@ -419,6 +419,25 @@ void oracle_intersect_batch(void* h, const float* rays, uint64_t n, float t_min,
     }
 }
 
+// For every (ray, sphere) pair: 1 when Sphere3::hit gets PAST its discriminant test (Sphere3.hpp:37-38), i.e.
+// `discriminant < 0` is false (NaN included).  A GPU-side filter may reject a sphere only when this is 0.
+void oracle_disc_pass(void* h, const float* rays, uint64_t n, uint8_t* out /* [n][scene size] */) {
+    Ctx& c = *static_cast<Ctx*>(h);
+    const size_t N = c.world.size();
+    for (uint64_t i = 0; i < n; ++i) {
+        const Ray r = {{rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]}, {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}};
+        for (size_t j = 0; j < N; ++j) {
+            const Sphere& s = c.world[j];
+            const V3 oc = sub(r.o, s.c);
+            const float a = length_squared(r.d);
+            const float half_b = dot(oc, r.d);
+            const float cc = length_squared(oc) - s.r * s.r;
+            const float discriminant = half_b * half_b - a * cc;
+            out[i * N + j] = (discriminant < 0.0f) ? 0 : 1;
+        }
+    }
+}
+
 // Sphere3::hit for ONE sphere per ray (sphere index given per ray).  out9 = p(3), normal(3), t,
 // front_face, hit.
 void oracle_sphere_hit_batch(void* h, const float* rays, const int32_t* sphere, uint64_t n, float t_min, float t_max,

@@ -46,6 +46,7 @@ def _load() -> C.CDLL:
     lib.oracle_get_scene.argtypes = [C.c_void_p] + [_f32p] * 10 + [_i32p]
     lib.oracle_camera.argtypes = [_f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
     lib.oracle_intersect_batch.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_float, C.c_float, _u8p, _i32p, _f32p]
+    lib.oracle_disc_pass.argtypes = [C.c_void_p, _f32p, C.c_uint64, _u8p]
     lib.oracle_sphere_hit_batch.argtypes = [C.c_void_p, _f32p, _i32p, C.c_uint64, C.c_float, C.c_float, _f32p]
     lib.oracle_scatter_batch.argtypes = [C.c_void_p, _f32p, _i32p, _f32p, _f32p, C.c_uint64, _f32p]
     lib.oracle_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _f32p]
@@ -136,6 +137,13 @@ class Oracle:
         t = np.zeros(n, np.float32)
         self._l.oracle_intersect_batch(self._h, rays, n, t_min, t_max, hit, idx, t)
         return hit, idx, t
+
+    def disc_pass(self, rays) -> np.ndarray:
+        """[n_rays, n_spheres] uint8: 1 where the reference's discriminant test lets the sphere through."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((rays.shape[0], self.n), np.uint8)
+        self._l.oracle_disc_pass(self._h, rays, rays.shape[0], out.reshape(-1))
+        return out
 
     def sphere_hit(self, rays, sphere, t_min=0.001, t_max=float("inf")):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtk.so")
+LIB_PATH = os.environ.get("RTK_LIB", os.path.join(HERE, "librtk.so"))   # RTK_LIB: A/B builds of the kernel (tools/)
 HOST_LIB_PATH = os.path.join(HERE, "librtiow_host.so")
 
 SCENE_FIELDS = ("cx", "cy", "cz", "radius", "mat_r", "mat_g", "mat_b", "roughness", "metallic", "ior", "mat_type")

@@ -1,9 +1,12 @@
 // rtk.hip — kernels and C ABI of librtk.so (see include/rtk.h for the contract and the reference
 // citations of every entry point).  gfx950 only; compiled with -ffp-contract=off (rtk_device.hpp).
 #include "rtk_device.hpp"
+#include "rtk_render.hpp"
+#include "rtk_scene_prep.hpp"
 
 #include "../../include/rtk.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,22 +20,6 @@ using namespace rtk;
 // =================================================================================================
 // Kernels
 // =================================================================================================
-
-struct RenderArgs {
-    SceneDev scene;
-    CameraDev cam;
-    int32_t W, H, spp, max_depth;
-    uint32_t seed_lo, seed_hi;
-    float t_min;
-    int32_t tile_w, tile_h, tiles_x;
-    int32_t rank, world;
-    int32_t n_local_tiles;
-    int32_t run_len, n_runs;
-    uint32_t total_packets;
-    unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
-    uint32_t* queue;             // packet counter
-    unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
-};
 
 // Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists.
 template <bool LDS>
@@ -56,7 +43,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     }
     it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
     it.n = sc.n;
-    it.nwords = sc.npad / 32;
+    it.fb = sc.fb;
     it.lane = lane;
     __syncthreads();
     return it;
@@ -64,149 +51,18 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 
 static size_t lds_bytes(bool lds, int npad) { return (lds ? static_cast<size_t>(npad) * 32 : 0) + kWavesPerBlock * kListCap * kWave * 2; }
 
-// Persistent wavefronts.  A packet = one 64-pixel tile x one run of `run_len` samples; a wavefront
-// draws packets from a global counter and hands the packet's 64 (pixel, run) units to whichever of
-// its lanes is free, so lanes whose path ended (sky, absorbed, depth exhausted) start the next sample
-// at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
-// run in fp32 and adds the run total once, as 32.32 fixed point, to the pixel's accumulator: integer
-// adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
 template <bool LDS>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);
-    const int lane = isect.lane;
-    const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
-
-    // lane state
-    Ray ray = {};
-    V3 thr = {0, 0, 0}, acc = {0, 0, 0};
-    bool alive = false, has_unit = false;
-    int depth_left = 0, unit_left = 0;
-    uint32_t pixel = 0, slot = 0, sample = 0, bounce = 0;
-    int px = 0, prow = 0;
-    uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
-    // wave state (uniform)
-    int pk_pos = kWave, pk_lt = 0, pk_run = 0;
-    bool queue_empty = false;
-    uint32_t wave_passes = 0;
-
-    for (;;) {
-        // ---- lanes without a live path: next sample of the unit, or retire the unit ----
-        bool start = false, need = false;
-        if (!alive) {
-            if (has_unit && unit_left > 0) {
-                --unit_left;
-                ++sample;
-                start = true;
-            } else {
-                if (has_unit) {
-                    // 32.32 fixed point; NaN contributes 0, magnitudes are clamped to +-2^30.
-                    const float lim = 0x1p30f;
-                    const float fr = fminf(fmaxf(acc.x, -lim), lim), fg = fminf(fmaxf(acc.y, -lim), lim), fb = fminf(fmaxf(acc.z, -lim), lim);
-                    const long long qr = (acc.x == acc.x) ? __double2ll_rn(static_cast<double>(fr) * 4294967296.0) : 0;
-                    const long long qg = (acc.y == acc.y) ? __double2ll_rn(static_cast<double>(fg) * 4294967296.0) : 0;
-                    const long long qb = (acc.z == acc.z) ? __double2ll_rn(static_cast<double>(fb) * 4294967296.0) : 0;
-                    unsigned long long* dst = A.accum + static_cast<size_t>(slot) * 3;
-                    atomicAdd(dst + 0, static_cast<unsigned long long>(qr));
-                    atomicAdd(dst + 1, static_cast<unsigned long long>(qg));
-                    atomicAdd(dst + 2, static_cast<unsigned long long>(qb));
-                    has_unit = false;
-                }
-                need = true;
-            }
-        }
-        // ---- hand out units of the wave's packet; draw a new packet when it runs dry ----
-        for (;;) {
-            const uint64_t nb = ballot(need);
-            if (nb == 0ull) break;
-            if (pk_pos >= kWave) {
-                if (queue_empty) break;
-                uint32_t q = 0;
-                if (lane == 0) q = atomicAdd(A.queue, 1u);
-                q = __builtin_amdgcn_readfirstlane(q);
-                if (q >= A.total_packets) {
-                    queue_empty = true;
-                    break;
-                }
-                pk_run = static_cast<int>(q / static_cast<uint32_t>(A.n_local_tiles));
-                pk_lt = static_cast<int>(q % static_cast<uint32_t>(A.n_local_tiles));
-                pk_pos = 0;
-            }
-            const int avail = kWave - pk_pos;
-            const int r = lane_prefix(nb);
-            if (need && r < avail) {
-                const int k = pk_pos + r;
-                const int gt = pk_lt * A.world + A.rank;
-                const int tx = gt % A.tiles_x, ty = gt / A.tiles_x;
-                px = tx * A.tile_w + k % A.tile_w;
-                prow = ty * A.tile_h + k / A.tile_w;
-                if (px < A.W && prow < A.H) {
-                    pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
-                    slot = static_cast<uint32_t>(pk_lt) * kWave + static_cast<uint32_t>(k);
-                    sample = static_cast<uint32_t>(pk_run) * static_cast<uint32_t>(A.run_len);
-                    const int left = A.spp - static_cast<int>(sample);
-                    unit_left = (left < A.run_len ? left : A.run_len) - 1;
-                    acc = {0, 0, 0};
-                    has_unit = true;
-                    start = true;
-                    need = false;
-                }
-                // a unit that falls outside the image is dropped; the lane asks again
-            }
-            const int took = __popcll(nb);
-            pk_pos += took < avail ? took : avail;
-        }
-        // ---- primary rays (main.cpp:69-71) ----
-        if (start) {
-            const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
-            const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
-            ray = primary_ray(A.cam, px, prow, A.W, A.H, u);
-            thr = {1.0f, 1.0f, 1.0f};
-            depth_left = A.max_depth;
-            bounce = 0;
-            alive = depth_left > 0;   // main.cpp:87-89: depth <= 0 gathers no light and traces nothing
-            ++n_samp;
-        }
-        if (!wave_any(alive)) {
-            if (!wave_any(has_unit)) break;
-            continue;
-        }
-        // ---- one segment: HittableList::hit (main.cpp:90) ----
-        float t;
-        int idx;
-        isect.closest_hit(ray, alive, A.t_min, std::numeric_limits<float>::infinity(), t, idx, n_exact);
-        ++wave_passes;
-        if (alive) {
-            ++n_seg;
-            if (idx < 0) {
-                acc = acc + thr * sky(ray.d);            // main.cpp:98-100
-                alive = false;
-            } else {
-                ++bounce;
-                const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, bounce, 0u), key);
-                const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
-                const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
-                Ray out;
-                const bool ok = hit_and_scatter(ray, t, ex, m0, m1, u, out);
-                thr = thr * V3{m0.x, m0.y, m0.z};        // main.cpp:93 (running product)
-                ray = out;
-                --depth_left;
-                alive = ok && depth_left > 0;            // main.cpp:95 / 87-89: absorbed or out of depth -> black
-            }
-        }
-    }
-    atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
-    atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
-    atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
-    if (lane == 0) atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
+    render_wave<LDS>(A, isect);
 }
 
 // accumulators -> fp32 sums, and clear them for the next frame.
 __global__ void finalize_kernel(unsigned long long* accum, float* out, size_t n) {
     const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
     if (i < n) {
-        const long long q = static_cast<long long>(accum[i]);
-        out[i] = static_cast<float>(static_cast<double>(q) * (1.0 / 4294967296.0));
+        out[i] = accum_to_float(accum[i]);
         accum[i] = 0ull;
     }
 }
@@ -219,7 +75,7 @@ __global__ void deinterleave_kernel(const float* g, long long tprp, int W, int H
     const int tx = x / tile_w, ty = row / tile_h;
     const int gt = ty * tiles_x + tx;
     const int k = (row % tile_h) * tile_w + (x % tile_w);
-    const long long src = ((static_cast<long long>(gt % world) * tprp + gt / world) * kWave + k) * 3;
+    const long long src = ((static_cast<long long>(gt % world) * tprp + gt / world) * kTilePixels + k) * 3;
     img[p * 3 + 0] = g[src + 0];
     img[p * 3 + 1] = g[src + 1];
     img[p * 3 + 2] = g[src + 2];
@@ -430,31 +286,11 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     if (!s->cx || !s->cy || !s->cz || !s->radius || !s->mat_r || !s->mat_g || !s->mat_b || !s->roughness || !s->metallic || !s->ior || !s->mat_type)
         return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null array");
     HIP_TRY(hipSetDevice(c->device));
-    const int n = s->n, npad = (n + 31) / 32 * 32;
-    std::vector<float4> filt(npad), exact(npad), m0(n), m1(n);
-    const float inf = std::numeric_limits<float>::infinity();
-    for (int i = 0; i < npad; ++i) {
-        if (i >= n) {
-            // pad: r^2 term of -inf makes the widened discriminant -inf for every finite ray
-            filt[i] = make_float4(0.f, 0.f, 0.f, -inf);
-            exact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        const float cx = s->cx[i], cy = s->cy[i], cz = s->cz[i], r = s->radius[i];
-        volatile float rr_v = r * r;                 // fl(radius*radius), Sphere3.hpp:35 (host compiler must not widen)
-        const float rr = rr_v;
-        exact[i] = make_float4(cx, cy, cz, rr);
-        const float big = 0x1p30f, ar = std::fabs(r);
-        const bool safe = std::fabs(cx) < big && std::fabs(cy) < big && std::fabs(cz) < big && ar > 0x1p-20f && ar < big;
-        // unsafe spheres (NaN/inf/huge/tiny) are candidates for every ray: centre 0, r^2 term +inf
-        filt[i] = safe ? make_float4(cx, cy, cz, rr * kFilterScaleSq) : make_float4(0.f, 0.f, 0.f, inf);
-        m0[i] = make_float4(s->mat_r[i], s->mat_g[i], s->mat_b[i], s->roughness[i]);
-        int32_t ty = s->mat_type[i];
-        float tyf;
-        std::memcpy(&tyf, &ty, 4);
-        volatile float inv_v = 1.0f / r;             // fl(1/radius), Vector3.cpp:36
-        m1[i] = make_float4(s->metallic[i], s->ior[i], tyf, inv_v);
-    }
+    PreparedScene ps;
+    prepare_scene(s, ps);
+    const int n = ps.n, npad = ps.npad;
+    const std::vector<float4>&filt = ps.filt, &exact = ps.exact, &m0 = ps.m0, &m1 = ps.m1;
+    const FilterBounds fb = ps.fb;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(c->filt.reserve(sizeof(float4) * npad));
     HIP_TRY(c->exact.reserve(sizeof(float4) * npad));
@@ -465,7 +301,7 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     HIP_TRY(hipMemcpy(c->mat0.p, m0.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat1.p, m1.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
-                static_cast<const float4*>(c->mat1.p), n, npad};
+                static_cast<const float4*>(c->mat1.p), n, npad, fb};
     c->have_scene = true;
     // persistent-grid sizing for both kernel flavours at this scene size
     for (int l = 0; l < 2; ++l) {
@@ -488,7 +324,7 @@ static int norm_tiles(const rtk_params* p, int& tw, int& th) {
     tw = p->tile_w;
     th = p->tile_h;
     if (tw == 0 && th == 0) { tw = 8; th = 8; }
-    if (tw <= 0 || th <= 0 || tw * th != kWave) return fail(RTK_ERR_BAD_ARG, "tile %d x %d: a tile must hold exactly 64 pixels", tw, th);
+    if (tw <= 0 || th <= 0 || tw * th != kTilePixels) return fail(RTK_ERR_BAD_ARG, "tile %d x %d: a tile must hold exactly 64 pixels", tw, th);
     return RTK_OK;
 }
 
@@ -525,7 +361,7 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     const int n_runs = (p->spp + run_len - 1) / run_len;
     const int64_t packets = nlt * n_runs;
     if (packets >= (1ll << 32) - (1ll << 20)) return fail(RTK_ERR_TOO_LARGE, "%lld packets exceed the 32-bit queue", static_cast<long long>(packets));
-    const size_t n_acc = static_cast<size_t>(nlt) * kWave * 3;
+    const size_t n_acc = static_cast<size_t>(nlt) * kTilePixels * 3;
     if (nlt == 0) return RTK_OK;
 
     if (n_acc * 8 > c->accum.cap) {
@@ -643,7 +479,7 @@ int rtk_render(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float
     q.rank = 0;
     const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, 0, 1);
     const size_t np = static_cast<size_t>(p->width) * p->height;
-    HIP_TRY(c->tile_out.reserve(static_cast<size_t>(nlt) * kWave * 3 * sizeof(float)));
+    HIP_TRY(c->tile_out.reserve(static_cast<size_t>(nlt) * kTilePixels * 3 * sizeof(float)));
     HIP_TRY(c->image_out.reserve(np * 3 * sizeof(float)));
     rtk_stats st;
     if (int e = rtk_render_tiles_device(c, cam, &q, static_cast<float*>(c->tile_out.p), &st)) return e;

@@ -9,14 +9,25 @@
 // Reference citations are relative to /root/reference/RayTracingInOneWeekend/.
 #pragma once
 
+#ifdef RTK_HOST_EMULATION
+// tests/cpu_emul/rtk_host_shim.hpp: a one-lane-per-wave CPU build of this header for the CPU test-suite
+// (test infrastructure; the shipped library never defines RTK_HOST_EMULATION).
+#include "rtk_host_shim.hpp"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
+
+#ifndef RTK_LANES
+#define RTK_LANES 64
+#endif
 
 namespace rtk {
 
-constexpr int kWave = 64;            // CDNA wavefront
-constexpr int kBlockThreads = 256;   // 4 waves per workgroup, one per SIMD
-constexpr int kWavesPerBlock = kBlockThreads / kWave;
+constexpr int kWave = RTK_LANES;     // CDNA wavefront (64); 1 in the CPU emulation build
+constexpr int kTilePixels = 64;      // a tile / packet always holds 64 pixels
+constexpr int kBlockThreads = 4 * kWave;   // 4 waves per workgroup, one per SIMD
+constexpr int kWavesPerBlock = 4;
 constexpr int kListCap = 16;         // per-lane candidate list entries between flushes
 constexpr int kMaxLdsSpheres = 1024; // scenes up to this size are LDS-resident (32 B per sphere)
 
@@ -92,6 +103,14 @@ __device__ __forceinline__ V3 sample_in_unit_sphere(float u1, float u2, float u3
 // ---------------------------------------------------------------------------------------------
 // Scene as the kernels see it.
 // ---------------------------------------------------------------------------------------------
+// Scene-wide bounds the projection-form filter needs (over the FILTERABLE spheres only; the others
+// carry r^2 = +inf in `filt` and are candidates for every ray).
+struct FilterBounds {
+    float c_max;     // max |C| + |r|
+    float r_max2;    // max r^2
+    float r_min;     // min |r|
+};
+
 struct SceneDev {
     const float4* filt;   // [npad] cx, cy, cz, r^2 (1+k): filter operands; pads never pass
     const float4* exact;  // [npad] cx, cy, cz, r*r  (fl(r*r), Sphere3.hpp:35)
@@ -99,6 +118,7 @@ struct SceneDev {
     const float4* mat1;   // [n] metallic, ior, type (int bits), 1/radius (fl(1/r), Vector3.cpp:36)
     int32_t n;
     int32_t npad;         // n rounded up to a multiple of 32
+    FilterBounds fb;
 };
 
 struct CameraDev {
@@ -147,14 +167,21 @@ __device__ __forceinline__ bool sphere_root_exact(const Ray& r, float a, float4 
 // Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
+#ifndef RTK_FILTER_FORM
+#define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test)
+#endif
+
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
+    FilterBounds fb;
     int n;
-    int nwords;
     int lane;
+#ifdef RTK_HOST_EMULATION
+    uint8_t* dbg_flags = nullptr;   // emulation only: [n] set to 1 for every sphere the filter passes to the exact stage
+#endif
 
     __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int& cnt, float& closest, int& best,
                                           uint32_t& n_exact) const {
@@ -173,53 +200,118 @@ struct Intersector {
         cnt = 0;
     }
 
+    // Per-ray operands of the filter.
+    struct FilterRay {
+#if RTK_FILTER_FORM == 0
+        float ox, oy, oz, dhx, dhy, dhz;
+#else
+        float e1x, e1y, e1z, ns1, e2x, e2y, e2z, ns2;
+#endif
+    };
+
+    // One ray-sphere filter test; shifts the result bit into `m` (form 0: 1 = certainly missed, form 1: 1 = candidate).
+    static __device__ __forceinline__ void filter_one(const FilterRay& f, float sx, float sy, float sz, float sw, uint32_t& m) {
+#if RTK_FILTER_FORM == 0
+        const float x = f.ox - sx, y = f.oy - sy, z = f.oz - sz;
+        const float hb = fmaf(z, f.dhz, fmaf(y, f.dhy, x * f.dhx));
+        const float c = fmaf(z, z, fmaf(y, y, fmaf(x, x, -sw)));
+        const float disc = fmaf(hb, hb, -c);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(disc), 31);
+#else
+        const float p1 = fmaf(sz, f.e1z, fmaf(sy, f.e1y, fmaf(sx, f.e1x, f.ns1)));
+        const float p2 = fmaf(sz, f.e2z, fmaf(sy, f.e2y, fmaf(sx, f.e2x, f.ns2)));
+        const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
+#endif
+    }
+
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
                                                 uint32_t& n_exact) const {
         // Reference `a` (Sphere3.hpp:33), hoisted.
         const float a = length_squared(r.d);
-        // Filter operands: d-hat widened by (1+2^-15).  v_rsq_f32 is 1 ulp; its error is far inside the margin.
-        const float inv_len = __builtin_amdgcn_rsqf(a) * kFilterScale;
-        const float dhx = r.d.x * inv_len, dhy = r.d.y * inv_len, dhz = r.d.z * inv_len;
         // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
         // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
         const float big = 0x1p30f;
         const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
-        const float ox = r.o.x, oy = r.o.y, oz = r.o.z;
-
+        FilterRay f;
+        const float inv_len = __builtin_amdgcn_rsqf(a);
+#if RTK_FILTER_FORM == 0
+        // d-hat widened by (1+2^-15).  v_rsq_f32 is 1 ulp; its error is far inside the margin.
+        f.ox = r.o.x; f.oy = r.o.y; f.oz = r.o.z;
+        f.dhx = r.d.x * (inv_len * kFilterScale); f.dhy = r.d.y * (inv_len * kFilterScale); f.dhz = r.d.z * (inv_len * kFilterScale);
+#else
+        // Orthonormal basis (e1, e2) of the plane perpendicular to the ray (Duff et al. 2017, branch-free);
+        // a sphere can only be hit if its centre, projected on that plane, lies within r of the ray.
+        // The projected distances are shrunk by g < 1 so that everything the reference's own rounding could
+        // still accept (E) and this filter's evaluation error (dp) stay inside r.
+        {
+            const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
+            const float sg = copysignf(1.0f, dz);
+            const float aa = -__builtin_amdgcn_rcpf(sg + dz);
+            const float bb = dx * dy * aa;
+            const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
+            const float M = o_len + fb.c_max;
+            const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
+            const float dp = 0x1p-19f * M;
+            const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
+            f.e1x = g * fmaf(sg * dx, dx * aa, 1.0f); f.e1y = g * (sg * bb); f.e1z = g * (-sg * dx);
+            f.e2x = g * bb; f.e2y = g * fmaf(dy, dy * aa, sg); f.e2z = g * (-dy);
+            f.ns1 = -fmaf(r.o.z, f.e1z, fmaf(r.o.y, f.e1y, r.o.x * f.e1x));
+            f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
+        }
+#endif
         float closest = t_max;
         int best = -1;
         int cnt = 0;
-        for (int w = 0; w < nwords; ++w) {
-            const float4* sp = filt + w * 32;
-            uint32_t m = 0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float4 s = sp[i];
-                const float x = ox - s.x, y = oy - s.y, z = oz - s.z;
-                const float hb = fmaf(z, dhz, fmaf(y, dhy, x * dhx));
-                const float c = fmaf(z, z, fmaf(y, y, fmaf(x, x, -s.w)));
-                const float disc = fmaf(hb, hb, -c);
-                m = __builtin_amdgcn_alignbit(m, __float_as_uint(disc), 31);   // shift the sign bit in
-            }
-            // bit (31-i) of m is set when sphere w*32+i is certainly missed.
-            const int left = n - w * 32;                                        // uniform
-            const uint32_t valid = left >= 32 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (32 - left));
-            uint32_t cand = (safe ? ~m : 0xFFFFFFFFu) & valid;
-            if (!active) cand = 0;
-            // compaction: candidate bits -> this lane's list (ascending index); when a lane's list is
-            // full the wave runs the exact stage early and carries on
+
+        // compaction: candidate bits (MSB = first sphere of the word) -> this lane's list, ascending index;
+        // when a lane's list is full the wave runs the exact stage early and carries on
+        auto emit = [&](int base, uint32_t cand) {
+#ifdef RTK_HOST_EMULATION
+            if (dbg_flags)
+                for (int b = 0; b < 32; ++b)
+                    if (cand & (0x80000000u >> b)) dbg_flags[base + b] = 1;
+#endif
             for (;;) {
                 while (wave_any(cand != 0 && cnt < kListCap)) {
                     if (cand != 0 && cnt < kListCap) {
                         const int pos = __clz(static_cast<int>(cand));
                         cand &= ~(0x80000000u >> pos);
-                        list[cnt * kWave + lane] = static_cast<uint16_t>(w * 32 + pos);
+                        list[cnt * kWave + lane] = static_cast<uint16_t>(base + pos);
                         ++cnt;
                     }
                 }
                 if (!wave_any(cand != 0)) break;
                 flush(r, a, t_min, cnt, closest, best, n_exact);
             }
+        };
+        auto to_cand = [&](uint32_t m, uint32_t valid) -> uint32_t {
+#if RTK_FILTER_FORM == 0
+            m = ~m;
+#endif
+            uint32_t cand = (safe ? m : 0xFFFFFFFFu) & valid;
+            return active ? cand : 0u;
+        };
+
+        const int full = n >> 5, rem = n & 31;
+        for (int w = 0; w < full; ++w) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float4 s = filt[w * 32 + i];
+                filter_one(f, s.x, s.y, s.z, s.w, m);
+            }
+            emit(w * 32, to_cand(m, 0xFFFFFFFFu));
+        }
+        if (rem) {
+            uint32_t m = 0;
+#pragma unroll 4
+            for (int i = 0; i < rem; ++i) {
+                const float4 s = filt[full * 32 + i];
+                filter_one(f, s.x, s.y, s.z, s.w, m);
+            }
+            m <<= (32 - rem);
+            emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
         }
         flush(r, a, t_min, cnt, closest, best, n_exact);
         t_out = closest;

@@ -1,0 +1,166 @@
+// rtk_render.hpp — the render loop of one wavefront (device code; also built for the CPU by the
+// emulation harness under tests/cpu_emul with one lane per wave).
+#pragma once
+
+#include "rtk_device.hpp"
+
+namespace rtk {
+
+struct RenderArgs {
+    SceneDev scene;
+    CameraDev cam;
+    int32_t W, H, spp, max_depth;
+    uint32_t seed_lo, seed_hi;
+    float t_min;
+    int32_t tile_w, tile_h, tiles_x;
+    int32_t rank, world;
+    int32_t n_local_tiles;
+    int32_t run_len, n_runs;
+    uint32_t total_packets;
+    unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
+    uint32_t* queue;             // packet counter
+    unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
+};
+
+// Persistent wavefronts.  A packet = one 64-pixel tile x one run of `run_len` samples; a wavefront
+// draws packets from a global counter and hands the packet's 64 (pixel, run) units to whichever of
+// its lanes is free, so lanes whose path ended (sky, absorbed, depth exhausted) start the next sample
+// at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
+// run in fp32 and adds the run total once, as 32.32 fixed point, to the pixel's accumulator: integer
+// adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
+template <bool LDS>
+__device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect) {
+    const int lane = isect.lane;
+    const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
+
+    // lane state
+    Ray ray = {};
+    V3 thr = {0, 0, 0}, acc = {0, 0, 0};
+    bool alive = false, has_unit = false;
+    int depth_left = 0, unit_left = 0;
+    uint32_t pixel = 0, slot = 0, sample = 0, bounce = 0;
+    int px = 0, prow = 0;
+    uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
+    // wave state (uniform)
+    int pk_pos = kTilePixels, pk_lt = 0, pk_run = 0;
+    bool queue_empty = false;
+    uint32_t wave_passes = 0;
+
+    for (;;) {
+        // ---- lanes without a live path: next sample of the unit, or retire the unit ----
+        bool start = false, need = false;
+        if (!alive) {
+            if (has_unit && unit_left > 0) {
+                --unit_left;
+                ++sample;
+                start = true;
+            } else {
+                if (has_unit) {
+                    // 32.32 fixed point; NaN contributes 0, magnitudes are clamped to +-2^30.
+                    const float lim = 0x1p30f;
+                    const float fr = fminf(fmaxf(acc.x, -lim), lim), fg = fminf(fmaxf(acc.y, -lim), lim), fb = fminf(fmaxf(acc.z, -lim), lim);
+                    const long long qr = (acc.x == acc.x) ? __double2ll_rn(static_cast<double>(fr) * 4294967296.0) : 0;
+                    const long long qg = (acc.y == acc.y) ? __double2ll_rn(static_cast<double>(fg) * 4294967296.0) : 0;
+                    const long long qb = (acc.z == acc.z) ? __double2ll_rn(static_cast<double>(fb) * 4294967296.0) : 0;
+                    unsigned long long* dst = A.accum + static_cast<size_t>(slot) * 3;
+                    atomicAdd(dst + 0, static_cast<unsigned long long>(qr));
+                    atomicAdd(dst + 1, static_cast<unsigned long long>(qg));
+                    atomicAdd(dst + 2, static_cast<unsigned long long>(qb));
+                    has_unit = false;
+                }
+                need = true;
+            }
+        }
+        // ---- hand out units of the wave's packet; draw a new packet when it runs dry ----
+        for (;;) {
+            const uint64_t nb = ballot(need);
+            if (nb == 0ull) break;
+            if (pk_pos >= kTilePixels) {
+                if (queue_empty) break;
+                uint32_t q = 0;
+                if (lane == 0) q = atomicAdd(A.queue, 1u);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q >= A.total_packets) {
+                    queue_empty = true;
+                    break;
+                }
+                pk_run = static_cast<int>(q / static_cast<uint32_t>(A.n_local_tiles));
+                pk_lt = static_cast<int>(q % static_cast<uint32_t>(A.n_local_tiles));
+                pk_pos = 0;
+            }
+            const int avail = kTilePixels - pk_pos;
+            const int r = lane_prefix(nb);
+            if (need && r < avail) {
+                const int k = pk_pos + r;
+                const int gt = pk_lt * A.world + A.rank;
+                const int tx = gt % A.tiles_x, ty = gt / A.tiles_x;
+                px = tx * A.tile_w + k % A.tile_w;
+                prow = ty * A.tile_h + k / A.tile_w;
+                if (px < A.W && prow < A.H) {
+                    pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
+                    slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
+                    sample = static_cast<uint32_t>(pk_run) * static_cast<uint32_t>(A.run_len);
+                    const int left = A.spp - static_cast<int>(sample);
+                    unit_left = (left < A.run_len ? left : A.run_len) - 1;
+                    acc = {0, 0, 0};
+                    has_unit = true;
+                    start = true;
+                    need = false;
+                }
+                // a unit that falls outside the image is dropped; the lane asks again
+            }
+            const int took = __popcll(nb);
+            pk_pos += took < avail ? took : avail;
+        }
+        // ---- primary rays (main.cpp:69-71) ----
+        if (start) {
+            const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
+            const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+            ray = primary_ray(A.cam, px, prow, A.W, A.H, u);
+            thr = {1.0f, 1.0f, 1.0f};
+            depth_left = A.max_depth;
+            bounce = 0;
+            alive = depth_left > 0;   // main.cpp:87-89: depth <= 0 gathers no light and traces nothing
+            ++n_samp;
+        }
+        if (!wave_any(alive)) {
+            if (!wave_any(has_unit)) break;
+            continue;
+        }
+        // ---- one segment: HittableList::hit (main.cpp:90) ----
+        float t;
+        int idx;
+        isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
+        ++wave_passes;
+        if (alive) {
+            ++n_seg;
+            if (idx < 0) {
+                acc = acc + thr * sky(ray.d);            // main.cpp:98-100
+                alive = false;
+            } else {
+                ++bounce;
+                const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, bounce, 0u), key);
+                const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+                const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
+                Ray out;
+                const bool ok = hit_and_scatter(ray, t, ex, m0, m1, u, out);
+                thr = thr * V3{m0.x, m0.y, m0.z};        // main.cpp:93 (running product)
+                ray = out;
+                --depth_left;
+                alive = ok && depth_left > 0;            // main.cpp:95 / 87-89: absorbed or out of depth -> black
+            }
+        }
+    }
+    atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
+    atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
+    atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
+    if (lane == 0) atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
+}
+
+
+// accumulator (signed 32.32 fixed point) -> fp32 colour sum
+__device__ __forceinline__ float accum_to_float(unsigned long long a) {
+    return static_cast<float>(static_cast<double>(static_cast<long long>(a)) * (1.0 / 4294967296.0));
+}
+
+} // namespace rtk

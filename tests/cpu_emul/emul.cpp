@@ -1,0 +1,159 @@
+// emul.cpp -> tests/cpu_emul/libemul.so: the DEVICE code of librtk (rtk_device.hpp, rtk_render.hpp) and its host
+// scene preparation (rtk_scene_prep.hpp) compiled for the CPU with one lane per wave (rtk_host_shim.hpp).
+// TEST INFRASTRUCTURE ONLY — lets `pytest -m "not gpu"` check the kernels' logic against the oracle.
+// Build: g++ -std=c++17 -O2 -ffp-contract=off -mfma -DRTK_HOST_EMULATION -DRTK_LANES=1 -I. -I<csrc> ...
+#include "rtk_device.hpp"
+#include "rtk_render.hpp"
+#include "rtk_scene_prep.hpp"
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace rtk_shim {
+thread_local int ulp_noise = 0;
+thread_local uint32_t noise_state = 12345u;
+}
+
+using namespace rtk;
+
+struct Emul {
+    PreparedScene ps;
+    SceneDev dev;
+};
+
+static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg) {
+    Intersector<false> it;
+    it.filt = e.ps.filt.data();
+    it.exact = e.ps.exact.data();
+    it.list = list;
+    it.fb = e.ps.fb;
+    it.n = e.ps.n;
+    it.lane = 0;
+    it.dbg_flags = dbg;
+    return it;
+}
+
+extern "C" {
+
+void* emul_create(const rtk_scene* s) {
+    Emul* e = new Emul();
+    prepare_scene(s, e->ps);
+    e->dev = {e->ps.filt.data(), e->ps.exact.data(), e->ps.m0.data(), e->ps.m1.data(), e->ps.n, e->ps.npad, e->ps.fb};
+    return e;
+}
+void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
+
+void emul_set_ulp_noise(int k) { rtk_shim::ulp_noise = k; }
+
+// filter bounds and per-sphere "filterable" flag as prepare_scene decided them
+void emul_scene_info(void* h, float* bounds3, uint8_t* filterable) {
+    const Emul& e = *static_cast<Emul*>(h);
+    bounds3[0] = e.ps.fb.c_max; bounds3[1] = e.ps.fb.r_max2; bounds3[2] = e.ps.fb.r_min;
+    for (int i = 0; i < e.ps.n; ++i) filterable[i] = std::isinf(e.ps.filt[i].w) ? 0 : 1;
+}
+
+// Intersector::closest_hit per ray; `flags` (optional, [n][scene size]) receives the filter's candidate flags.
+void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t_max, uint8_t* hit, int32_t* index, float* t, uint8_t* flags,
+                    uint64_t* n_exact_total, int ulp_noise) {
+    const Emul& e = *static_cast<Emul*>(h);
+    rtk_shim::ulp_noise = ulp_noise;
+    uint16_t list[kListCap * kWave];
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const Intersector<false> it = make_isect(e, list, flags ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr);
+        const float* q = rays + 6 * i;
+        const Ray r = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+        float tt;
+        int idx;
+        uint32_t ne = 0;
+        it.closest_hit(r, true, t_min, t_max, tt, idx, ne);
+        total += ne;
+        hit[i] = idx >= 0;
+        index[i] = idx;
+        t[i] = idx >= 0 ? tt : 0.0f;
+    }
+    if (n_exact_total) *n_exact_total = total;
+    rtk_shim::ulp_noise = 0;
+}
+
+void emul_scatter(void* h, const float* rays, const int32_t* index, const float* t, const float* u4, uint64_t n, float* out7) {
+    const Emul& e = *static_cast<Emul*>(h);
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* q = rays + 6 * i;
+        const Ray in = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+        const int idx = index[i];
+        const float u[4] = {u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3]};
+        Ray out;
+        const bool ok = hit_and_scatter(in, t[i], e.ps.exact[idx], e.ps.m0[idx], e.ps.m1[idx], u, out);
+        float* o = out7 + 7 * i;
+        o[0] = out.o.x; o[1] = out.o.y; o[2] = out.o.z; o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z; o[6] = ok ? 1.0f : 0.0f;
+    }
+}
+
+void emul_primary(const float* cam22, int W, int H, uint64_t seed, const int32_t* xys, uint64_t n, float* out) {
+    CameraDev cam;
+    std::memcpy(&cam, cam22, 88);
+    for (uint64_t i = 0; i < n; ++i) {
+        const int x = xys[3 * i], row = xys[3 * i + 1], s = xys[3 * i + 2];
+        const uint32_t pixel = static_cast<uint32_t>(row) * static_cast<uint32_t>(W) + static_cast<uint32_t>(x);
+        const uint4 rnd = philox4x32_10(make_uint4(pixel, static_cast<uint32_t>(s), 0u, 0u), make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)));
+        const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
+        const Ray r = primary_ray(cam, x, row, W, H, u);
+        float* o = out + 6 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+    }
+}
+
+void emul_philox(uint64_t seed, const uint32_t* ctr4, uint64_t n, uint32_t* out4) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint4 r = philox4x32_10(make_uint4(ctr4[4 * i], ctr4[4 * i + 1], ctr4[4 * i + 2], ctr4[4 * i + 3]),
+                                      make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)));
+        out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+    }
+}
+
+// render_wave on `threads` CPU threads (each one "wavefront" of one lane) for rank `p->rank` of `p->world_size`;
+// writes this rank's tile sums [local tile][64][3] like rtk_render_tiles_device.  stats4 = rays, samples, exact tests, passes.
+int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* tile_sums, uint64_t* stats4, int threads) {
+    const Emul& e = *static_cast<Emul*>(h);
+    const int world = p->world_size > 0 ? p->world_size : 1;
+    int tw = p->tile_w, th = p->tile_h;
+    if (tw == 0 && th == 0) { tw = 8; th = 8; }
+    if (tw * th != kTilePixels) return -1;
+    const int tiles_x = (p->width + tw - 1) / tw;
+    const int64_t tiles = static_cast<int64_t>(tiles_x) * ((p->height + th - 1) / th);
+    const int64_t nlt = (tiles - p->rank + world - 1) / world;
+    const int run_len = p->run_len > 0 ? (p->run_len < p->spp ? p->run_len : p->spp) : (p->spp < 8 ? p->spp : 8);
+    const int n_runs = (p->spp + run_len - 1) / run_len;
+    std::vector<unsigned long long> accum(static_cast<size_t>(nlt) * kTilePixels * 3, 0ull);
+    uint32_t queue = 0;
+    unsigned long long stats[4] = {0, 0, 0, 0};
+    RenderArgs A;
+    A.scene = e.dev;
+    std::memcpy(&A.cam, cam22, 88);
+    A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_depth = p->max_depth;
+    A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
+    A.t_min = p->t_min;
+    A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
+    A.rank = p->rank; A.world = world;
+    A.n_local_tiles = static_cast<int32_t>(nlt);
+    A.run_len = run_len; A.n_runs = n_runs;
+    A.total_packets = static_cast<uint32_t>(nlt * n_runs);
+    A.accum = accum.data();
+    A.queue = &queue;
+    A.stats = stats;
+    std::vector<std::thread> pool;
+    for (int k = 0; k < threads; ++k)
+        pool.emplace_back([&] {
+            uint16_t list[kListCap * kWave];
+            const Intersector<false> it = make_isect(e, list, nullptr);
+            render_wave<false>(A, it);
+        });
+    for (auto& t : pool) t.join();
+    for (size_t i = 0; i < accum.size(); ++i) tile_sums[i] = accum_to_float(accum[i]);
+    for (int i = 0; i < 4; ++i) stats4[i] = stats[i];
+    return 0;
+}
+
+} // extern "C"

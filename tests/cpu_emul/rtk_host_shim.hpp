@@ -1,0 +1,70 @@
+// rtk_host_shim.hpp — lets raytracinginoneweekend_amd/csrc/rtk_device.hpp and rtk_render.hpp compile with g++
+// as a ONE-LANE-PER-WAVE CPU program (RTK_HOST_EMULATION, RTK_LANES=1).  TEST INFRASTRUCTURE ONLY: it exists so
+// the device logic (filter conservativeness, compaction, exact stage, shading, work distribution) can be checked
+// against the oracle in the CPU test-suite; the shipped library never includes it and has no CPU path.
+//
+// Lanes of a wavefront interact only through votes (ballot / any) and lane-private list slots, so with one lane
+// per wave every vote degenerates to the lane's own predicate and the per-lane results are exactly those of the
+// 64-lane kernel.  Hardware approximations (v_rsq_f32, v_rcp_f32, v_sqrt_f32, v_sin/cos, v_exp/log) are
+// modelled by libm plus an optional adversarial +-ulp perturbation (emul_set_ulp_noise).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+
+struct float4 { float x, y, z, w; };
+struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return {x, y, z, w}; }
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return {x, y}; }
+
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return static_cast<uint32_t>((static_cast<uint64_t>(a) * b) >> 32); }
+inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz(static_cast<unsigned>(x)); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline long long __double2ll_rn(double d) { return std::llrint(d); }
+inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+namespace rtk_shim {
+extern thread_local int ulp_noise;      // 0: libm values; k > 0: pseudo-random perturbation within +-k ulp
+extern thread_local uint32_t noise_state;
+inline float nudge(float x) {
+    if (ulp_noise == 0 || !(x == x) || std::isinf(x) || x == 0.0f) return x;
+    noise_state = noise_state * 1664525u + 1013904223u;
+    const int k = static_cast<int>((noise_state >> 16) % static_cast<uint32_t>(2 * ulp_noise + 1)) - ulp_noise;
+    uint32_t u; std::memcpy(&u, &x, 4);
+    u = static_cast<uint32_t>(static_cast<int32_t>(u) + k);
+    float y; std::memcpy(&y, &u, 4);
+    return y;
+}
+inline float rsqf(float x) { return nudge(static_cast<float>(1.0 / std::sqrt(static_cast<double>(x)))); }
+inline float rcpf(float x) { return nudge(static_cast<float>(1.0 / static_cast<double>(x))); }
+inline float sqrtf_(float x) { return nudge(std::sqrt(x)); }
+inline float sin_rev(float x) { return nudge(static_cast<float>(std::sin(6.283185307179586 * static_cast<double>(x)))); }
+inline float cos_rev(float x) { return nudge(static_cast<float>(std::cos(6.283185307179586 * static_cast<double>(x)))); }
+inline float exp2f_(float x) { return nudge(std::exp2(x)); }
+inline float log2f_(float x) { return nudge(std::log2(x)); }
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (sh & 31)); }
+} // namespace rtk_shim
+
+#define __builtin_amdgcn_rsqf(x) rtk_shim::rsqf(x)
+#define __builtin_amdgcn_rcpf(x) rtk_shim::rcpf(x)
+#define __builtin_amdgcn_sqrtf(x) rtk_shim::sqrtf_(x)
+#define __builtin_amdgcn_sinf(x) rtk_shim::sin_rev(x)
+#define __builtin_amdgcn_cosf(x) rtk_shim::cos_rev(x)
+#define __builtin_amdgcn_exp2f(x) rtk_shim::exp2f_(x)
+#define __builtin_amdgcn_logf(x) rtk_shim::log2f_(x)
+#define __builtin_amdgcn_alignbit(a, b, c) rtk_shim::alignbit(a, b, c)
+#define __builtin_amdgcn_mbcnt_lo(m, v) (v)
+#define __builtin_amdgcn_mbcnt_hi(m, v) (v)
+#define __builtin_amdgcn_readfirstlane(x) (x)

@@ -1,0 +1,108 @@
+"""ctypes view of tests/cpu_emul/libemul.so: the librtk DEVICE code compiled for the CPU (one lane per wave).
+Test infrastructure; see tests/cpu_emul/rtk_host_shim.hpp."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import raytracinginoneweekend_amd as rt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "cpu_emul", "libemul.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-C", os.path.join(HERE, "cpu_emul")], check=True, capture_output=True)
+        l = C.CDLL(LIB)
+        vp = C.c_void_p
+        l.emul_create.restype = vp
+        l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]
+        l.emul_destroy.argtypes = [vp]
+        l.emul_scene_info.argtypes = [vp, vp, vp]
+        l.emul_intersect.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int]
+        l.emul_scatter.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
+        l.emul_primary.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, vp, C.c_uint64, vp]
+        l.emul_philox.argtypes = [C.c_uint64, vp, C.c_uint64, vp]
+        l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int]
+        _lib = l
+    return _lib
+
+
+class Emul:
+    def __init__(self, scene: dict):
+        self._l = lib()
+        arrs = {k: np.ascontiguousarray(scene[k], np.float32) for k in rt.SCENE_FIELDS[:10]}
+        arrs["mat_type"] = np.ascontiguousarray(scene["mat_type"], np.int32)
+        s = rt.rtk_scene()
+        s.n = len(arrs["cx"])
+        for k in rt.SCENE_FIELDS[:10]:
+            setattr(s, k, arrs[k].ctypes.data_as(C.POINTER(C.c_float)))
+        s.mat_type = arrs["mat_type"].ctypes.data_as(C.POINTER(C.c_int32))
+        self.n = s.n
+        self._h = C.c_void_p(self._l.emul_create(C.byref(s)))
+
+    def __del__(self):
+        try:
+            self._l.emul_destroy(self._h)
+        except Exception:
+            pass
+
+    def scene_info(self):
+        b = np.zeros(3, np.float32)
+        f = np.zeros(self.n, np.uint8)
+        self._l.emul_scene_info(self._h, b.ctypes.data, f.ctypes.data)
+        return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2])}, f
+
+    def intersect(self, rays, t_min=0.001, t_max=float("inf"), want_flags=False, ulp_noise=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        hit = np.zeros(n, np.uint8); idx = np.zeros(n, np.int32); t = np.zeros(n, np.float32)
+        flags = np.zeros((n, self.n), np.uint8) if want_flags else None
+        ne = C.c_uint64(0)
+        self._l.emul_intersect(self._h, rays.ctypes.data, n, t_min, t_max, hit.ctypes.data, idx.ctypes.data, t.ctypes.data,
+                               flags.ctypes.data if want_flags else None, C.addressof(ne), ulp_noise)
+        self.last_exact = ne.value
+        return (hit, idx, t, flags) if want_flags else (hit, idx, t)
+
+    def scatter(self, rays, index, t, u4):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        index = np.ascontiguousarray(index, np.int32); t = np.ascontiguousarray(t, np.float32)
+        u4 = np.ascontiguousarray(u4, np.float32).reshape(n, 4)
+        out = np.zeros((n, 7), np.float32)
+        self._l.emul_scatter(self._h, rays.ctypes.data, index.ctypes.data, t.ctypes.data, u4.ctypes.data, n, out.ctypes.data)
+        return out
+
+    def render_tiles(self, cam22, params, threads=8):
+        nlt = rt.local_tile_count(params.width, params.height, params.rank, max(1, params.world_size), params.tile_w or 8, params.tile_h or 8)
+        out = np.zeros((nlt, 64, 3), np.float32)
+        st = np.zeros(4, np.uint64)
+        cam = np.ascontiguousarray(cam22, np.float32)
+        rc = self._l.emul_render_tiles(self._h, cam.ctypes.data, C.byref(params), out.ctypes.data, st.ctypes.data, threads)
+        assert rc == 0
+        return out, {"rays": int(st[0]), "samples": int(st[1]), "exact_tests": int(st[2]), "passes": int(st[3])}
+
+    def render(self, cam22, W, H, spp, depth, seed=0, threads=8, run_len=0, tile_w=8, tile_h=8):
+        from np_mirror import deinterleave
+        p = rt.make_params(W, H, spp, depth, seed, 0.001, 0, 1, tile_w, tile_h, run_len)
+        tiles, st = self.render_tiles(cam22, p, threads)
+        return deinterleave(tiles[None], W, H, 1, tile_w, tile_h), st
+
+
+def primary_rays(cam22, W, H, xys, seed=0):
+    xys = np.ascontiguousarray(xys, np.int32).reshape(-1, 3)
+    out = np.zeros((xys.shape[0], 6), np.float32)
+    cam = np.ascontiguousarray(cam22, np.float32)
+    lib().emul_primary(cam.ctypes.data, W, H, seed, xys.ctypes.data, xys.shape[0], out.ctypes.data)
+    return out
+
+
+def philox(seed, ctr4):
+    ctr4 = np.ascontiguousarray(ctr4, np.uint32).reshape(-1, 4)
+    out = np.zeros_like(ctr4)
+    lib().emul_philox(seed, ctr4.ctypes.data, ctr4.shape[0], out.ctypes.data)
+    return out

@@ -1,0 +1,185 @@
+"""The librtk DEVICE code (filter -> compaction -> exact) compiled for the CPU with one lane per wave
+(tests/cpu_emul), checked against the reference fixtures and the oracle WITHOUT a GPU:
+
+* parity: hit / index / t of Intersector::closest_hit == HittableList::hit, bit for bit;
+* conservativeness: every (ray, sphere) pair that gets past the reference's discriminant test
+  (Sphere3.hpp:37-38, NaN included) is passed on by the filter — in every regime, including origins so far
+  away that the reference's own rounding noise accepts spheres the ray misses geometrically, and with the
+  hardware approximations (v_rsq / v_rcp / v_sqrt) perturbed by up to +-3 ulp.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, load_golden
+import raytracinginoneweekend_amd as rt
+from emul import Emul
+from oracle import pyoracle as po
+from test_oracle_golden import ties_scene
+
+
+def check(scene, rays, t_min=0.001, t_max=np.inf, noises=(0, 3), want=None):
+    e = Emul(scene)
+    o = po.Oracle()
+    o.set_scene(scene)
+    ho, io, to = want if want is not None else o.intersect(rays, t_min, t_max)
+    dp = o.disc_pass(rays)
+    nan = np.isnan(to)
+    over = 0.0
+    for noise in noises:
+        hit, idx, t, flags = e.intersect(rays, t_min, t_max, want_flags=True, ulp_noise=noise)
+        assert int(((dp == 1) & (flags == 0)).sum()) == 0, "the filter rejected a sphere the reference lets through"
+        assert np.array_equal(hit, ho) and np.array_equal(idx, io)
+        assert np.array_equal(np.isnan(t), nan) and np.array_equal(bits(t)[~nan], bits(to)[~nan])
+        over = flags.sum() / max(1, dp.sum())
+    return over
+
+
+@pytest.mark.parametrize("batch", ["primary", "secondary", "tertiary", "random", "grazing", "inside", "degenerate"])
+def test_fixed_batches_vs_reference(stock_scene_golden, batch):
+    z = load_golden("rays_stock.npz")
+    over = check(stock_scene_golden, z[batch + "_rays"], want=(z[batch + "_hit"], z[batch + "_index"], z[batch + "_t"]))
+    assert over < 1.35          # the filter's extra candidates stay a small fraction of the reference's own
+
+
+def test_finite_range_and_ties(stock_scene_golden):
+    z = load_golden("rays_stock.npz")
+    check(stock_scene_golden, z["primary_rays"], 0.5, 9.0, want=(z["primary_tmin0p5_tmax9_hit"], z["primary_tmin0p5_tmax9_index"], z["primary_tmin0p5_tmax9_t"]))
+    t = load_golden("rays_ties.npz")
+    check(ties_scene(t), t["rays"], want=(t["hit"], t["index"], t["t"]))
+
+
+def tangent_rays(rng, scene, n, dist_lo, dist_hi, rel_eps, first=0):
+    """Rays from `dist` away aimed at the silhouette of a random sphere, +- rel_eps radii; unnormalised."""
+    N = len(scene["cx"])
+    k = rng.integers(first, N, n)
+    c = np.stack([scene["cx"][k], scene["cy"][k], scene["cz"][k]], 1).astype(np.float64)
+    r = np.abs(scene["radius"][k].astype(np.float64))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = np.exp(rng.uniform(np.log(dist_lo), np.log(dist_hi), n)) + r
+    o = c + u * dist[:, None]
+    w = -u
+    a = rng.normal(size=(n, 3)); a -= (a * w).sum(1, keepdims=True) * w; a /= np.linalg.norm(a, axis=1, keepdims=True)
+    s = np.clip(r * (1 + rel_eps * rng.uniform(-1, 1, n)) / dist, 0, 0.999)
+    d = w * np.sqrt(1 - s * s)[:, None] + a * s[:, None]
+    d *= np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (n, 1)))
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("lo,hi", [(0.01, 1), (1, 30), (30, 300), (300, 3000), (3000, 1e5), (1e5, 1e8)])
+def test_tangent_rays_at_every_distance(stock_scene_golden, lo, hi):
+    """Beyond a few hundred units the reference's c = |oc|^2 - r^2 is pure rounding noise and it 'hits' spheres the
+    ray misses by far; the filter must pass all of those too (its margin scales with the same |oc|^2)."""
+    rng = np.random.default_rng(int(lo * 100) + 1)
+    for eps in (0.0, 1e-6, 1e-3, 0.3):
+        check(stock_scene_golden, tangent_rays(rng, stock_scene_golden, 1500, lo, hi, eps, first=1))
+
+
+def test_random_rays_bulk(stock_scene_golden):
+    rng = np.random.default_rng(5)
+    n = 150_000
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-14, 14, (n, 3)); rays[:, 1] = rng.uniform(0.001, 3, n)
+    rays[:, 3:6] = rng.normal(size=(n, 3)) * rng.uniform(1e-3, 1e3, (n, 1))
+    s = stock_scene_golden
+    m = n // 3
+    k = rng.integers(0, 484, m)
+    nrm = rng.normal(size=(m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rays[:m, 0:3] = np.stack([s["cx"][k], s["cy"][k], s["cz"][k]], 1) + nrm * s["radius"][k][:, None]   # on surfaces
+    rays[:m, 3:6] = nrm + rng.normal(size=(m, 3)) * rng.choice([1.0, 0.1, 1e-3], (m, 1))
+    check(stock_scene_golden, rays, noises=(3,))
+
+
+def _odd_scene(rng, n, scale=1.0, offset=(0, 0, 0)):
+    s = {"cx": rng.uniform(-10, 10, n) * scale + offset[0], "cy": rng.uniform(0, 2, n) * scale + offset[1],
+         "cz": rng.uniform(-10, 10, n) * scale + offset[2], "radius": rng.uniform(0.05, 1.0, n) * scale}
+    s = {k: v.astype(np.float32) for k, v in s.items()}
+    for k in ("mat_r", "mat_g", "mat_b", "roughness", "metallic", "ior"):
+        s[k] = np.ones(n, np.float32)
+    s["mat_type"] = np.ones(n, np.int32)
+    return s
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 1025])
+def test_scene_sizes_and_tail_word(n):
+    rng = np.random.default_rng(n)
+    s = _odd_scene(rng, n)
+    m = 4000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    check(s, rays)
+    check(s, tangent_rays(rng, s, 2000, 0.5, 200, 1e-5))
+
+
+@pytest.mark.parametrize("scale,offset", [(1e-3, (0, 0, 0)), (1e3, (0, 0, 0)), (1.0, (1e4, -3e3, 500)), (1e-2, (50, 50, 50)), (1e6, (0, 0, 0)), (1e-6, (0, 0, 0))])
+def test_scaled_and_translated_scenes(scale, offset):
+    """The margins are relative (to |o| + scene extent), so tiny, huge and far-from-origin scenes stay exact."""
+    rng = np.random.default_rng(11)
+    s = _odd_scene(rng, 200, scale, offset)
+    m = 4000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-12, 12, (m, 3)) * scale + np.array(offset)
+    rays[:, 3:6] = rng.normal(size=(m, 3)) * scale
+    check(s, rays)
+    check(s, tangent_rays(rng, s, 3000, 0.5 * scale, 500 * scale, 1e-5))
+
+
+def test_unsafe_spheres_specks_and_negative_radius():
+    rng = np.random.default_rng(3)
+    s = _odd_scene(rng, 60)
+    s["radius"][3] = -0.7
+    s["radius"][5] = np.inf
+    s["cx"][7] = np.nan
+    s["radius"][9] = 1e-30
+    s["cy"][11] = 3e38
+    s["radius"][13] = 0.0
+    s["radius"][15] = np.nan
+    s["cz"][17] = -np.inf
+    s["radius"][19] = 1e25
+    s["cx"][21] = 2e9
+    s["radius"][23] = 1e-4         # a speck among unit-size spheres
+    s["radius"][25] = 3e-5
+    s["radius"][27] = 500.0        # a second giant
+    e = Emul(s)
+    info, filterable = e.scene_info()
+    assert not filterable[[5, 7, 9, 11, 13, 15, 17, 19, 21]].any()
+    assert info["r_min"] >= 0.04 and info["c_max"] < 100        # specks and giants were peeled off the bounds
+    m = 20000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    rays[::7, 0:3] = (s["cx"][9], s["cy"][9], s["cz"][9])
+    rays[::11, 0:3] = (s["cx"][13], s["cy"][13], s["cz"][13])
+    rays[::13, 0:3] = (s["cx"][23], s["cy"][23], s["cz"][23]) + rng.normal(size=(len(rays[::13]), 3)) * 1e-4
+    check(s, rays)
+    ok = np.array([i for i in range(60) if np.isfinite(s["radius"][i]) and abs(s["radius"][i]) > 0 and np.isfinite(s["cx"][i] + s["cy"][i] + s["cz"][i]) and abs(s["cx"][i]) < 1e6 and abs(s["cy"][i]) < 1e6 and abs(s["radius"][i]) < 1e6])
+    sub = {k: v[ok] for k, v in s.items()}
+    check(sub, tangent_rays(rng, sub, 5000, 0.01, 100, 1e-5))
+
+
+def test_many_tiny_spheres_do_not_break_exactness():
+    """More specks than the outlier peeling removes: r_min is small, the filter degrades to 'many candidates'
+    but results stay exact."""
+    rng = np.random.default_rng(4)
+    s = _odd_scene(rng, 120)
+    s["radius"][:40] = rng.uniform(1e-4, 1e-3, 40).astype(np.float32)
+    m = 5000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    check(s, rays)
+    check(s, tangent_rays(rng, s, 5000, 0.01, 50, 1e-4))
+
+
+def test_large_scene_config4():
+    s = rt.scaled_scene(k=50)
+    rng = np.random.default_rng(9)
+    m = 1500
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-50, 50, m); rays[:, 1] = rng.uniform(0.01, 4, m); rays[:, 2] = rng.uniform(-50, 50, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.2
+    check(s, rays, noises=(3,))
+
+
+def test_candidate_lists_overflow_path(stock_scene_golden):
+    """Degenerate (unsafe) rays make all 484 spheres candidates: the 16-entry lane list is flushed 31 times and
+    the running closest / NaN behaviour must survive the early exact passes."""
+    z = load_golden("rays_stock.npz")
+    e = Emul(stock_scene_golden)
+    hit, idx, t, flags = e.intersect(z["degenerate_rays"], want_flags=True)
+    assert (flags.sum(1) == 484).sum() > 20
+    assert e.last_exact >= flags.sum()

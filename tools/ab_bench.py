@@ -1,0 +1,20 @@
+"""A/B the kernel variants under raytracinginoneweekend_amd/variants/ in one process each, interleaved rounds.
+usage: python tools/ab_bench.py [spp] [rounds]   (run on the GPU box)"""
+import glob, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spp = sys.argv[1] if len(sys.argv) > 1 else "100"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+libs = sorted(glob.glob(os.path.join(ROOT, "raytracinginoneweekend_amd", "variants", "*.so")))
+res = {}
+for r in range(rounds):
+    for lib in libs:
+        env = dict(os.environ, RTK_LIB=lib)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--spp", spp, "--no-cpu-baseline"],
+                             env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(os.path.basename(lib), "FAILED", out.stderr[-400:]); continue
+        j = json.loads(line[-1])
+        res.setdefault(os.path.basename(lib), []).append((j["value"], j["roofline"]["frac"], j["roofline"]["exact_tests_per_ray"], j["roofline"]["lane_utilisation"]))
+for k, v in res.items():
+    print("%-28s Mrays/s %s  frac %s  exact/ray %.2f util %.3f" % (k, ["%.0f" % x[0] for x in v], ["%.3f" % x[1] for x in v], v[0][2], v[0][3]))
