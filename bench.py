@@ -42,6 +42,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
+KERNEL_TAG = "r01-b (projection filter, decreasing run schedule)"
 
 
 def cpu_baseline():
@@ -148,7 +149,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                # only a measurement of THIS kernel build counts (the tag is bumped whenever the kernel's memory behaviour changes)
+                traffic = tj.get("bytes_per_launch") if tj.get("kernel_tag") == KERNEL_TAG else None
             except Exception:
                 traffic = None
         out = {

@@ -81,7 +81,8 @@ typedef struct rtk_params {
     int32_t world_size;   /* ... of the row-major grid of tile_w x tile_h pixel tiles */
     int32_t tile_w;       /* tile_w * tile_h must be 64 (one wavefront of pixels); 0,0 -> 8 x 8 */
     int32_t tile_h;
-    int32_t run_len;      /* samples a lane accumulates in fp32 before one fixed-point add; 0 -> default */
+    int32_t run_len;      /* > 0: a lane sums runs of this many samples in fp32 before one fixed-point add;
+                           * 0: the default decreasing partition, see rtk_run_schedule */
 } rtk_params;
 
 /* What one render did.  `rays` counts ray SEGMENTS = calls of HittableList::hit (main.cpp:90),
@@ -123,6 +124,13 @@ int rtk_set_scene(rtk_context* ctx, const rtk_scene* scene);
 /* Number of tiles rank `rank` of `world_size` owns for a width x height image. */
 int64_t rtk_local_tile_count(int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, int32_t rank,
                              int32_t world_size);
+
+/* The partition of the spp samples of a pixel into runs that a render of (spp, width, height, run_len) uses:
+ * n pairs (first sample, length) into out_pairs (2 * cap uint32), returns n (out_pairs may be NULL to query n).
+ * Pure host function (no device needed).  The partition never depends on rank or world_size, which is what
+ * keeps images bit-identical across GPU counts; no counterpart in the reference (its sample loop is serial,
+ * main.cpp:68). */
+int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len, uint32_t* out_pairs, int32_t cap);
 
 /* main.cpp:64-76 for the tiles of p->rank: per-pixel fp32 colour sums over spp samples, written to
  * DEVICE memory `d_tile_sums` as [local tile][tile_h][tile_w][3] floats (local tile k is global tile

@@ -24,6 +24,7 @@ C_ABI_SYMBOLS = (
     "rtk_set_scene", "rtk_local_tile_count", "rtk_render_tiles_device", "rtk_deinterleave_device", "rtk_render",
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
+    "rtk_run_schedule",
 )
 
 
@@ -96,6 +97,7 @@ def lib() -> C.CDLL:
         l.rtk_synchronize.argtypes = [vp]
         l.rtk_reset_stats.argtypes = [vp]
         l.rtk_get_stats.argtypes = [vp, C.POINTER(rtk_stats)]
+        l.rtk_run_schedule.argtypes = [i32, i32, i32, i32, vp, i32]
         _lib = l
     return _lib
 
@@ -156,6 +158,16 @@ def camera(look_from, look_at, vup, vfov, aspect, aperture, focus) -> np.ndarray
 def stock_camera(aspect: float) -> np.ndarray:
     """Camera of main.cpp:48-54."""
     return camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, aspect, 0.1, 10.0)
+
+
+def run_schedule(spp: int, W: int, H: int, run_len: int = 0) -> np.ndarray:
+    """[n_runs, 2] (first sample, length): how a render of this size splits a pixel's samples (host only)."""
+    n = lib().rtk_run_schedule(spp, W, H, run_len, None, 0)
+    if n < 0:
+        raise RtkError(lib().rtk_last_error().decode())
+    out = np.zeros((n, 2), np.uint32)
+    _check(min(0, lib().rtk_run_schedule(spp, W, H, run_len, out.ctypes.data, n)), "rtk_run_schedule")
+    return out
 
 
 def local_tile_count(W, H, rank=0, world=1, tile_w=8, tile_h=8) -> int:

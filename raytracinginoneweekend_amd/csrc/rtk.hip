@@ -203,6 +203,9 @@ struct rtk_context {
     SceneDev scene = {};
     bool have_scene = false;
     DevBuf filt, exact, mat0, mat1;
+    DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
+    std::vector<uint2> runs_host;
+    int runs_key[4] = {-1, -1, -1, -1};
     DevBuf accum;        // fixed-point accumulators
     size_t accum_zeroed = 0;   // number of accumulators known to be zero
     DevBuf control;      // queue counter (256 B) + stats
@@ -255,7 +258,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -335,12 +338,15 @@ int64_t rtk_local_tile_count(int32_t W, int32_t H, int32_t tile_w, int32_t tile_
     return (tiles - rank + world - 1) / world;
 }
 
-static int default_run_len(int spp) {
-    // long enough that the three fixed-point adds per run are noise, short enough that the units
-    // still in flight when the queue empties are a small tail
-    int r = 8;
-    if (r > spp) r = spp;
-    return r < 1 ? 1 : r;
+int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len, uint32_t* out_pairs, int32_t cap) {
+    if (spp <= 0 || width <= 0 || height <= 0 || run_len < 0) return fail(RTK_ERR_BAD_ARG, "rtk_run_schedule: spp %d, image %d x %d, run_len %d", spp, width, height, run_len);
+    const std::vector<uint2> runs = run_schedule(spp, width, height, run_len);
+    const int n = static_cast<int>(runs.size());
+    if (out_pairs) {
+        if (cap < n) return fail(RTK_ERR_BAD_ARG, "rtk_run_schedule: %d runs do not fit in %d pairs", n, cap);
+        for (int i = 0; i < n; ++i) { out_pairs[2 * i] = runs[i].x; out_pairs[2 * i + 1] = runs[i].y; }
+    }
+    return n;
 }
 
 int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats) {
@@ -357,8 +363,16 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
 
     const int tiles_x = (p->width + tw - 1) / tw;
     const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, p->rank, world);
-    const int run_len = p->run_len > 0 ? (p->run_len < p->spp ? p->run_len : p->spp) : default_run_len(p->spp);
-    const int n_runs = (p->spp + run_len - 1) / run_len;
+    if (p->run_len < 0) return fail(RTK_ERR_BAD_ARG, "run_len must be >= 0, got %d", p->run_len);
+    if (c->runs_key[0] != p->spp || c->runs_key[1] != p->width || c->runs_key[2] != p->height || c->runs_key[3] != p->run_len) {
+        // a new sample partition: upload its table (the stream may still be reading the old one)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->runs_host = run_schedule(p->spp, p->width, p->height, p->run_len);
+        HIP_TRY(c->runs.reserve(c->runs_host.size() * sizeof(uint2)));
+        HIP_TRY(hipMemcpy(c->runs.p, c->runs_host.data(), c->runs_host.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        c->runs_key[0] = p->spp; c->runs_key[1] = p->width; c->runs_key[2] = p->height; c->runs_key[3] = p->run_len;
+    }
+    const int n_runs = static_cast<int>(c->runs_host.size());
     const int64_t packets = nlt * n_runs;
     if (packets >= (1ll << 32) - (1ll << 20)) return fail(RTK_ERR_TOO_LARGE, "%lld packets exceed the 32-bit queue", static_cast<long long>(packets));
     const size_t n_acc = static_cast<size_t>(nlt) * kTilePixels * 3;
@@ -388,7 +402,7 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
     A.rank = p->rank; A.world = world;
     A.n_local_tiles = static_cast<int32_t>(nlt);
-    A.run_len = run_len; A.n_runs = n_runs;
+    A.runs = static_cast<const uint2*>(c->runs.p); A.n_runs = n_runs;
     A.total_packets = static_cast<uint32_t>(packets);
     A.accum = static_cast<unsigned long long*>(c->accum.p);
     A.queue = static_cast<uint32_t*>(c->control.p);

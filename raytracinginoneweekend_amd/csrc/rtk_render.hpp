@@ -15,14 +15,18 @@ struct RenderArgs {
     int32_t tile_w, tile_h, tiles_x;
     int32_t rank, world;
     int32_t n_local_tiles;
-    int32_t run_len, n_runs;
+    const uint2* runs;           // [n_runs] (first sample, length) of every run, rtk_scene_prep.hpp run_schedule()
+    int32_t n_runs;
     uint32_t total_packets;
     unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
     uint32_t* queue;             // packet counter
     unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
+#ifdef RTK_HOST_EMULATION
+    uint8_t* dbg_seg = nullptr;  // emulation only: [pixel][spp] segments traced per sample (work-distribution studies)
+#endif
 };
 
-// Persistent wavefronts.  A packet = one 64-pixel tile x one run of `run_len` samples; a wavefront
+// Persistent wavefronts.  A packet = one 64-pixel tile x one run of consecutive samples; a wavefront
 // draws packets from a global counter and hands the packet's 64 (pixel, run) units to whichever of
 // its lanes is free, so lanes whose path ended (sky, absorbed, depth exhausted) start the next sample
 // at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
@@ -99,9 +103,9 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 if (px < A.W && prow < A.H) {
                     pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
                     slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
-                    sample = static_cast<uint32_t>(pk_run) * static_cast<uint32_t>(A.run_len);
-                    const int left = A.spp - static_cast<int>(sample);
-                    unit_left = (left < A.run_len ? left : A.run_len) - 1;
+                    const uint2 run = A.runs[pk_run];
+                    sample = run.x;
+                    unit_left = static_cast<int>(run.y) - 1;
                     acc = {0, 0, 0};
                     has_unit = true;
                     start = true;
@@ -134,6 +138,9 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         ++wave_passes;
         if (alive) {
             ++n_seg;
+#ifdef RTK_HOST_EMULATION
+            if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + sample];
+#endif
             if (idx < 0) {
                 acc = acc + thr * sky(ray.d);            // main.cpp:98-100
                 alive = false;

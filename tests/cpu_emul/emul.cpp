@@ -115,7 +115,7 @@ void emul_philox(uint64_t seed, const uint32_t* ctr4, uint64_t n, uint32_t* out4
 
 // render_wave on `threads` CPU threads (each one "wavefront" of one lane) for rank `p->rank` of `p->world_size`;
 // writes this rank's tile sums [local tile][64][3] like rtk_render_tiles_device.  stats4 = rays, samples, exact tests, passes.
-int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* tile_sums, uint64_t* stats4, int threads) {
+int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* tile_sums, uint64_t* stats4, int threads, uint8_t* seg_counts) {
     const Emul& e = *static_cast<Emul*>(h);
     const int world = p->world_size > 0 ? p->world_size : 1;
     int tw = p->tile_w, th = p->tile_h;
@@ -124,8 +124,8 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     const int tiles_x = (p->width + tw - 1) / tw;
     const int64_t tiles = static_cast<int64_t>(tiles_x) * ((p->height + th - 1) / th);
     const int64_t nlt = (tiles - p->rank + world - 1) / world;
-    const int run_len = p->run_len > 0 ? (p->run_len < p->spp ? p->run_len : p->spp) : (p->spp < 8 ? p->spp : 8);
-    const int n_runs = (p->spp + run_len - 1) / run_len;
+    const std::vector<uint2> runs = run_schedule(p->spp, p->width, p->height, p->run_len);
+    const int n_runs = static_cast<int>(runs.size());
     std::vector<unsigned long long> accum(static_cast<size_t>(nlt) * kTilePixels * 3, 0ull);
     uint32_t queue = 0;
     unsigned long long stats[4] = {0, 0, 0, 0};
@@ -138,11 +138,12 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
     A.rank = p->rank; A.world = world;
     A.n_local_tiles = static_cast<int32_t>(nlt);
-    A.run_len = run_len; A.n_runs = n_runs;
+    A.runs = runs.data(); A.n_runs = n_runs;
     A.total_packets = static_cast<uint32_t>(nlt * n_runs);
     A.accum = accum.data();
     A.queue = &queue;
     A.stats = stats;
+    A.dbg_seg = seg_counts;
     std::vector<std::thread> pool;
     for (int k = 0; k < threads; ++k)
         pool.emplace_back([&] {

@@ -27,7 +27,7 @@ def lib():
         l.emul_scatter.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
         l.emul_primary.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, vp, C.c_uint64, vp]
         l.emul_philox.argtypes = [C.c_uint64, vp, C.c_uint64, vp]
-        l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int]
+        l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int, vp]
         _lib = l
     return _lib
 
@@ -77,12 +77,13 @@ class Emul:
         self._l.emul_scatter(self._h, rays.ctypes.data, index.ctypes.data, t.ctypes.data, u4.ctypes.data, n, out.ctypes.data)
         return out
 
-    def render_tiles(self, cam22, params, threads=8):
+    def render_tiles(self, cam22, params, threads=8, seg_counts=None):
         nlt = rt.local_tile_count(params.width, params.height, params.rank, max(1, params.world_size), params.tile_w or 8, params.tile_h or 8)
         out = np.zeros((nlt, 64, 3), np.float32)
         st = np.zeros(4, np.uint64)
         cam = np.ascontiguousarray(cam22, np.float32)
-        rc = self._l.emul_render_tiles(self._h, cam.ctypes.data, C.byref(params), out.ctypes.data, st.ctypes.data, threads)
+        rc = self._l.emul_render_tiles(self._h, cam.ctypes.data, C.byref(params), out.ctypes.data, st.ctypes.data, threads,
+                                          seg_counts.ctypes.data if seg_counts is not None else None)
         assert rc == 0
         return out, {"rays": int(st[0]), "samples": int(st[1]), "exact_tests": int(st[2]), "passes": int(st[3])}
 

@@ -57,3 +57,21 @@ def test_null_arguments_are_rejected_without_a_device():
 def test_no_device_fails_loudly():
     with pytest.raises(rt.RtkError, match="no CPU fallback"):
         rt.Context(0)
+
+
+def test_run_schedule_partitions_the_samples():
+    """rtk_run_schedule (host only): runs tile [0, spp) exactly, never depend on rank/world, shrink towards the end."""
+    import numpy as np
+    for spp, W, H, rl in [(500, 1200, 800, 0), (1000, 3840, 2160, 0), (10, 400, 225, 0), (1, 16, 16, 0), (500, 120, 80, 0), (500, 1200, 800, 8), (7, 64, 48, 3), (40, 64, 48, 40), (5, 64, 48, 9)]:
+        r = rt.run_schedule(spp, W, H, rl)
+        assert r[0, 0] == 0 and (r[:, 1] >= 1).all()
+        assert np.array_equal(r[1:, 0], np.cumsum(r[:, 1])[:-1]) and r[:, 1].sum() == spp
+        if rl == 0:
+            assert (np.diff(r[:, 1].astype(int)) <= 0).all()          # decreasing
+            assert r[-1, 1] == 1 or spp < 8                            # the frame ends on single-sample units
+        else:
+            assert (r[:-1, 1] == min(rl, spp)).all()
+    # C2: k = 64 -> first run 7 samples, about 200 runs; C3: k = 9 -> first run 111 samples
+    assert rt.run_schedule(500, 1200, 800)[0, 1] == 7 and 150 < len(rt.run_schedule(500, 1200, 800)) < 260
+    assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 111
+    assert rt.lib().rtk_run_schedule(0, 10, 10, 0, None, 0) == -1
