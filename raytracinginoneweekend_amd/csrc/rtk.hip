@@ -126,7 +126,7 @@ __global__ void scatter_kernel(const SceneDev sc, const float* rays, const int32
     const int idx = index[i];
     const float u[4] = {u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3]};
     Ray out;
-    const bool ok = hit_and_scatter(in, t[i], sc.exact[idx], sc.mat0[idx], sc.mat1[idx], u, out);
+    const bool ok = hit_and_scatter(in, unit_vector(in.d), t[i], sc.exact[idx], sc.mat0[idx], sc.mat1[idx], u, out);
     float* o = out7 + 7 * i;
     o[0] = out.o.x; o[1] = out.o.y; o[2] = out.o.z; o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z;
     o[6] = ok ? 1.0f : 0.0f;
@@ -400,6 +400,8 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
     A.t_min = p->t_min;
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
+    A.tile_w_log2 = 0;
+    while ((1 << A.tile_w_log2) < tw) ++A.tile_w_log2;
     A.rank = p->rank; A.world = world;
     A.n_local_tiles = static_cast<int32_t>(nlt);
     A.runs = static_cast<const uint2*>(c->runs.p); A.n_runs = n_runs;

@@ -321,7 +321,8 @@ struct Intersector {
 
 // hit_record construction (Sphere3.hpp:51-56, Hittable.hpp:15-18) + Material::scatter
 // (Material.cpp:6-54).  u = four uniforms in [0,1).  Returns scatter's bool; `out` is the scattered ray.
-__device__ __forceinline__ bool hit_and_scatter(const Ray& in, float t, float4 ex /*cx,cy,cz,rr*/, float4 m0, float4 m1,
+// `ud` = unit_vector(in.d), evaluated once by the caller.
+__device__ __forceinline__ bool hit_and_scatter(const Ray& in, const V3 ud, float t, float4 ex /*cx,cy,cz,rr*/, float4 m0, float4 m1,
                                                 const float u[4], Ray& out) {
     const V3 center = {ex.x, ex.y, ex.z};
     const V3 p = in.o + t * in.d;                       // Ray3.hpp:19-21
@@ -332,22 +333,21 @@ __device__ __forceinline__ bool hit_and_scatter(const Ray& in, float t, float4 e
     const float roughness = m0.w, metallic = m1.x, ior = m1.y;
     if (type == 1) {                                    // Lambertian, Material.cpp:8-19
         V3 dir = normal + roughness * sample_unit_vector(u[0], u[1]);
-        // near_zero (Vector3.cpp:138-141): the reference compares |x| promoted to double with 1e-8.
-        const double eps = 1e-8;
-        if (static_cast<double>(fabsf(dir.x)) < eps && static_cast<double>(fabsf(dir.y)) < eps &&
-            static_cast<double>(fabsf(dir.z)) < eps)
-            dir = normal;
+        // near_zero (Vector3.cpp:138-141): the reference compares |x| promoted to double with the double 1e-8.
+        // The largest float below 1e-8 is 0x322BCC77 (9.99999993922529e-09) and the next one is above it, so for
+        // an fp32 x:  (double)|x| < 1e-8  <=>  |x| <= 0x322BCC77  (checked exhaustively in tests/test_emul_render.py).
+        const float eps = __uint_as_float(0x322BCC77u);
+        if (fabsf(dir.x) <= eps && fabsf(dir.y) <= eps && fabsf(dir.z) <= eps) dir = normal;
         out = {p, dir};
         return true;
     }
     if (type == 2) {                                    // Metal, Material.cpp:20-25
-        const V3 dir = metallic * reflect(unit_vector(in.d), normal);
+        const V3 dir = metallic * reflect(ud, normal);
         out = {p, dir + roughness * sample_in_unit_sphere(u[0], u[1], u[2])};
         return dot(out.d, normal) > 0.0f;
     }
     if (type == 3) {                                    // Glass, Material.cpp:26-48
         const float ratio = front_face ? (1.0f / ior) : ior;
-        const V3 ud = unit_vector(in.d);
         const float cos_theta = fminf(dot(-ud, normal), 1.0f);
         const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
         const bool cannot_refract = ratio * sin_theta > 1.0f;
@@ -379,9 +379,8 @@ __device__ __forceinline__ Ray primary_ray(const CameraDev& cam, int x, int row,
     return r;
 }
 
-// Sky of main.cpp:98-100.
-__device__ __forceinline__ V3 sky(const V3 d) {
-    const V3 ud = unit_vector(d);
+// Sky of main.cpp:98-100 for the unit direction ud = unit_vector(r.direction()).
+__device__ __forceinline__ V3 sky_unit(const V3 ud) {
     const float t = 0.5f * (ud.y + 1.0f);
     return (1.0f - t) * V3{1.0f, 1.0f, 1.0f} + t * V3{0.5f, 0.7f, 1.0f};
 }

@@ -13,6 +13,7 @@ struct RenderArgs {
     uint32_t seed_lo, seed_hi;
     float t_min;
     int32_t tile_w, tile_h, tiles_x;
+    int32_t tile_w_log2;         // tile_w * tile_h == 64, so tile_w is a power of two
     int32_t rank, world;
     int32_t n_local_tiles;
     const uint2* runs;           // [n_runs] (first sample, length) of every run, rtk_scene_prep.hpp run_schedule()
@@ -46,7 +47,8 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     int px = 0, prow = 0;
     uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
     // wave state (uniform)
-    int pk_pos = kTilePixels, pk_lt = 0, pk_run = 0;
+    int pk_pos = kTilePixels, pk_lt = 0, pk_x0 = 0, pk_y0 = 0;
+    uint32_t pk_first = 0, pk_len = 1;
     bool queue_empty = false;
     uint32_t wave_passes = 0;
 
@@ -88,24 +90,27 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                     queue_empty = true;
                     break;
                 }
-                pk_run = static_cast<int>(q / static_cast<uint32_t>(A.n_local_tiles));
+                // per-packet (wave-uniform) quantities: run of samples, tile origin
+                const uint2 run = A.runs[q / static_cast<uint32_t>(A.n_local_tiles)];
+                pk_first = run.x;
+                pk_len = run.y;
                 pk_lt = static_cast<int>(q % static_cast<uint32_t>(A.n_local_tiles));
+                const int gt = pk_lt * A.world + A.rank;
+                pk_x0 = (gt % A.tiles_x) * A.tile_w;
+                pk_y0 = (gt / A.tiles_x) * A.tile_h;
                 pk_pos = 0;
             }
             const int avail = kTilePixels - pk_pos;
             const int r = lane_prefix(nb);
             if (need && r < avail) {
                 const int k = pk_pos + r;
-                const int gt = pk_lt * A.world + A.rank;
-                const int tx = gt % A.tiles_x, ty = gt / A.tiles_x;
-                px = tx * A.tile_w + k % A.tile_w;
-                prow = ty * A.tile_h + k / A.tile_w;
+                px = pk_x0 + (k & (A.tile_w - 1));
+                prow = pk_y0 + (k >> A.tile_w_log2);
                 if (px < A.W && prow < A.H) {
                     pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
                     slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
-                    const uint2 run = A.runs[pk_run];
-                    sample = run.x;
-                    unit_left = static_cast<int>(run.y) - 1;
+                    sample = pk_first;
+                    unit_left = static_cast<int>(pk_len) - 1;
                     acc = {0, 0, 0};
                     has_unit = true;
                     start = true;
@@ -137,12 +142,14 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
         ++wave_passes;
         if (alive) {
+            // unit_vector(r.direction()) of main.cpp:98 / Material.cpp:22,36 — one evaluation serves sky, metal and glass
+            const V3 ud = unit_vector(ray.d);
             ++n_seg;
 #ifdef RTK_HOST_EMULATION
             if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + sample];
 #endif
             if (idx < 0) {
-                acc = acc + thr * sky(ray.d);            // main.cpp:98-100
+                acc = acc + thr * sky_unit(ud);            // main.cpp:98-100
                 alive = false;
             } else {
                 ++bounce;
@@ -150,7 +157,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
                 const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
                 Ray out;
-                const bool ok = hit_and_scatter(ray, t, ex, m0, m1, u, out);
+                const bool ok = hit_and_scatter(ray, ud, t, ex, m0, m1, u, out);
                 thr = thr * V3{m0.x, m0.y, m0.z};        // main.cpp:93 (running product)
                 ray = out;
                 --depth_left;

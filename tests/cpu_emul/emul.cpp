@@ -85,7 +85,7 @@ void emul_scatter(void* h, const float* rays, const int32_t* index, const float*
         const int idx = index[i];
         const float u[4] = {u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3]};
         Ray out;
-        const bool ok = hit_and_scatter(in, t[i], e.ps.exact[idx], e.ps.m0[idx], e.ps.m1[idx], u, out);
+        const bool ok = hit_and_scatter(in, unit_vector(in.d), t[i], e.ps.exact[idx], e.ps.m0[idx], e.ps.m1[idx], u, out);
         float* o = out7 + 7 * i;
         o[0] = out.o.x; o[1] = out.o.y; o[2] = out.o.z; o[3] = out.d.x; o[4] = out.d.y; o[5] = out.d.z; o[6] = ok ? 1.0f : 0.0f;
     }
@@ -136,6 +136,8 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
     A.t_min = p->t_min;
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;
+    A.tile_w_log2 = 0;
+    while ((1 << A.tile_w_log2) < tw) ++A.tile_w_log2;
     A.rank = p->rank; A.world = world;
     A.n_local_tiles = static_cast<int32_t>(nlt);
     A.runs = runs.data(); A.n_runs = n_runs;

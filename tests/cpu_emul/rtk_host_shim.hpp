@@ -29,6 +29,7 @@ inline uint32_t __umulhi(uint32_t a, uint32_t b) { return static_cast<uint32_t>(
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz(static_cast<unsigned>(x)); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline long long __double2ll_rn(double d) { return std::llrint(d); }
 inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }

@@ -132,3 +132,10 @@ def test_depth_and_run_length(stock_emul):
     b, sb = stock_emul.render(cam, 24, 16, 20, 50, seed=8, run_len=1)
     c, sc = stock_emul.render(cam, 24, 16, 20, 50, seed=8, run_len=7)
     assert sa["rays"] == sb["rays"] == sc["rays"] and np.allclose(a, b, rtol=1e-5, atol=1e-5) and np.allclose(a, c, rtol=1e-5, atol=1e-5)
+
+
+def test_near_zero_threshold_is_exact_in_fp32():
+    """rtk_device.hpp replaces the reference's `(double)|x| < 1e-8` (Vector3.cpp:138-141) by `|x| <= 0x322BCC77`."""
+    u = np.arange(0x322BC000, 0x322BD000, dtype=np.uint32)
+    x = u.view(np.float32)
+    assert np.array_equal(x.astype(np.float64) < 1e-8, u <= 0x322BCC77)
