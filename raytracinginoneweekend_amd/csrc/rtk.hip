@@ -25,6 +25,7 @@ using namespace rtk;
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
+    it.filt_global = sc.filt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {

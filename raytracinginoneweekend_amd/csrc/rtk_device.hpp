@@ -171,9 +171,25 @@ __device__ __forceinline__ bool sphere_root_exact(const Ray& r, float a, float4 
 #define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test)
 #endif
 
+// RTK_SMEM=1 (experiment build, NOT the shipped default, never timed yet): the filter reads its sphere operands
+// with scalar loads from the GLOBAL copy of `filt` through the constant address space, so they arrive as SGPR
+// operands: no LDS traffic and no broadcast VGPR writes.  The pointer cast is only ever applied to `filt_global`
+// (device global memory, read-only for the kernel's lifetime) — never to an LDS address.
+#ifndef RTK_SMEM
+#define RTK_SMEM 0
+#endif
+#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
+typedef float rtk_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
+#define RTK_FILT_LOAD(i) (reinterpret_cast<rtk_const_f4_ptr>(reinterpret_cast<uintptr_t>(filt_global))[i])
+#else
+#define RTK_FILT_LOAD(i) (filt[i])
+#endif
+
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
+    const float4* filt_global;   // always the global-memory copy (RTK_SMEM reads through it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
     FilterBounds fb;
@@ -298,7 +314,7 @@ struct Intersector {
             uint32_t m = 0;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const float4 s = filt[w * 32 + i];
+                const auto s = RTK_FILT_LOAD(w * 32 + i);
                 filter_one(f, s.x, s.y, s.z, s.w, m);
             }
             emit(w * 32, to_cand(m, 0xFFFFFFFFu));
@@ -307,7 +323,7 @@ struct Intersector {
             uint32_t m = 0;
 #pragma unroll 4
             for (int i = 0; i < rem; ++i) {
-                const float4 s = filt[full * 32 + i];
+                const auto s = RTK_FILT_LOAD(full * 32 + i);
                 filter_one(f, s.x, s.y, s.z, s.w, m);
             }
             m <<= (32 - rem);

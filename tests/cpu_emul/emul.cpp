@@ -25,6 +25,7 @@ struct Emul {
 static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg) {
     Intersector<false> it;
     it.filt = e.ps.filt.data();
+    it.filt_global = e.ps.filt.data();
     it.exact = e.ps.exact.data();
     it.list = list;
     it.fb = e.ps.fb;
