@@ -11,7 +11,9 @@
 #include "Sphere3.hpp"
 #include "rtk.h"
 
+#include <cstdint>
 #include <memory>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -81,6 +83,18 @@ inline HittableList random_scene() {
 }
 
 namespace rtiow {
+
+// The reference's output file in one write: header of main.cpp:60 + write_color_binary's bytes (Color.hpp:28-48)
+// for every pixel of `rgb_sum` ([height][width][3], row 0 = top row).  Byte-identical to streaming the pixels through
+// write_color_binary one by one (3 ostream::write calls per pixel in the reference).
+inline void write_ppm_binary(std::ostream& out, int image_width, int image_height, const float* rgb_sum, int samples_per_pixel) {
+    out << "P6\n" << image_width << ' ' << image_height << '\n' << 255 << '\n';
+    const size_t n = static_cast<size_t>(image_width) * image_height * 3;
+    std::vector<char> bytes(n);
+    for (size_t i = 0; i < n; ++i)
+        bytes[i] = static_cast<char>(static_cast<uint8_t>(255 * rtiow_detail::gamma2(rgb_sum[i], samples_per_pixel)));
+    out.write(bytes.data(), static_cast<std::streamsize>(n));
+}
 
 struct RenderResult {
     std::vector<float> rgb_sum;   // [height][width][3], row 0 = top image row

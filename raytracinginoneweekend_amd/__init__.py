@@ -117,6 +117,8 @@ def host_lib() -> C.CDLL:
         h.rtiow_host_camera.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
         h.rtiow_host_list_hit.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, fp, C.c_uint64, C.c_float, C.c_float, up, ip, fp]
         h.rtiow_host_write_color_binary.argtypes = [fp, C.c_uint64, C.c_int, up]
+        h.rtiow_host_write_ppm.argtypes = [C.c_int, C.c_int, fp, C.c_int, up, C.c_int64]
+        h.rtiow_host_write_ppm.restype = C.c_int64
         h.rtiow_host_cpu_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, up]
         _host = h
     return _host

@@ -134,6 +134,16 @@ void rtiow_host_write_color_binary(const float* sums, uint64_t npixels, int spp,
     std::memcpy(out, s.data(), s.size());
 }
 
+// write_ppm_binary (Render.hpp): whole file image into `out` (capacity `cap`), returns its size.
+int64_t rtiow_host_write_ppm(int W, int H, const float* sums, int spp, uint8_t* out, int64_t cap) {
+    std::ostringstream os(std::ios_base::binary);
+    rtiow::write_ppm_binary(os, W, H, sums, spp);
+    const std::string s = os.str();
+    if (static_cast<int64_t>(s.size()) > cap) return -static_cast<int64_t>(s.size());
+    std::memcpy(out, s.data(), s.size());
+    return static_cast<int64_t>(s.size());
+}
+
 // The reference program on the host classes, CPU only (main.cpp:64-76 with ray_color): first call in
 // a process only (RNG statics).  For pinning the host API against the golden PPM hashes.
 void rtiow_host_cpu_render(int W, int H, int spp, int depth, float aspect, uint8_t* out_u8) {

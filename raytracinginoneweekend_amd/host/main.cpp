@@ -39,15 +39,13 @@ int main(int argc, char** argv) {
     Camera camera{Point3{13.0f, 2.0f, 3.0f}, Point3{0.0f, 0.0f, 0.0f}, Vector3{0.0f, 1.0f, 0.0f}, 20, aspect_ratio, 0.1f, 10.0f};
 
     std::ofstream bin_file("image_binary.ppm", std::ios_base::binary);
-    bin_file << "P6\n" << image_width << ' ' << image_height << '\n' << 255 << '\n';
     try {
         rtiow::RenderResult frame;
         {
             PROFILE_LOG_SCOPE("Image Generation");
             std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
             frame = rtiow::render_image(world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device);
-            for (size_t i = 0; i < frame.rgb_sum.size(); i += 3)
-                write_color_binary(bin_file, Color{frame.rgb_sum[i], frame.rgb_sum[i + 1], frame.rgb_sum[i + 2]}, samples_per_pixel);
+            rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
             std::cerr << "\rScanlines remaining: 0 \nDone.\n";
         }
         std::cerr << "rays " << frame.stats.rays << "  kernel " << frame.stats.kernel_ms << " ms  "

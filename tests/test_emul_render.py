@@ -139,3 +139,15 @@ def test_near_zero_threshold_is_exact_in_fp32():
     u = np.arange(0x322BC000, 0x322BD000, dtype=np.uint32)
     x = u.view(np.float32)
     assert np.array_equal(x.astype(np.float64) < 1e-8, u <= 0x322BCC77)
+
+
+def test_material_none_absorbs(stock_scene_golden):
+    """Material::Type::None (make_material, Material.cpp:49-52,56-63): scatter returns false -> the path is black."""
+    s = {k: v.copy() for k, v in stock_scene_golden.items()}
+    s["mat_type"][:] = 0
+    e = Emul(s)
+    img, st = e.render(rt.stock_camera(1.5), 24, 16, 8, 50, seed=1)
+    assert not img[-1].any() and img[0].min() > 0                 # ground rows black, sky rows lit
+    assert st["rays"] == st["samples"]                            # every path ends at its first hit or in the sky
+    out = e.scatter(np.array([[0, 5, 0, 0, -1, 0]], np.float32), np.array([481], np.int32), np.array([3.0], np.float32), np.zeros((1, 4), np.float32))
+    assert out[0, 6] == 0.0

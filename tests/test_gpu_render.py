@@ -197,3 +197,24 @@ def test_render_argument_errors(gpu_ctx):
         gpu_ctx.render(cam, 16, 16, 1, 1, tile_w=8, tile_h=4)
     with pytest.raises(rt.RtkError, match="spp"):
         gpu_ctx.render(cam, 16, 16, 0, 1)
+
+
+def test_context_reuse_and_material_none(stock_scene_golden):
+    """One context, several scenes one after another (HittableList::clear()/add() on the host side means a new
+    rtk_set_scene), and Material::Type::None absorbing every path it meets."""
+    ctx = rt.Context(0)
+    cam = rt.stock_camera(1.5)
+    small = {k: v[:40].copy() for k, v in stock_scene_golden.items()}
+    ctx.set_scene(small)
+    a, _ = ctx.render(cam, 48, 32, 8, 50, seed=2)
+    ctx.set_scene(stock_scene_golden)
+    b, sb = ctx.render(cam, 48, 32, 8, 50, seed=2)
+    ctx.set_scene(small)
+    a2, _ = ctx.render(cam, 48, 32, 8, 50, seed=2)
+    assert np.array_equal(bits(a), bits(a2)) and not np.array_equal(a, b)
+    none = {k: v.copy() for k, v in stock_scene_golden.items()}
+    none["mat_type"][:] = 0
+    ctx.set_scene(none)
+    img, st = ctx.render(cam, 48, 32, 8, 50, seed=2)
+    assert st["rays"] == st["samples"] and not img[-1].any() and img[0].min() > 0
+    ctx.close()

@@ -75,3 +75,13 @@ def test_scaled_scene_sizes():
     g = rt.scaled_scene(k=11, diffuse_below=0.1, metal_below=0.5, seed=7)
     frac = np.bincount(g["mat_type"], minlength=4) / len(g["cx"])
     assert frac[3] > 0.4 and frac[2] > 0.3 and frac[1] < 0.2
+
+
+def test_write_ppm_binary_is_the_reference_file():
+    """One-write PPM == header of main.cpp:60 + write_color_binary per pixel (reference fixture bytes)."""
+    z = load_golden("quantise.npz")
+    W, H = 37, 23
+    sums = np.ascontiguousarray(z["sums"][: W * H * 3])
+    out = np.zeros(W * H * 3 + 64, np.uint8)
+    n = rt.host_lib().rtiow_host_write_ppm(W, H, sums, int(z["spp"]), out, len(out))
+    assert out[:n].tobytes() == b"P6\n37 23\n255\n" + z["bytes"][: W * H * 3].tobytes()
