@@ -286,7 +286,7 @@ int rtk_synchronize(rtk_context* c) {
 int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     if (!c || !s) return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null argument");
     if (s->n <= 0) return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: scene has %d spheres", s->n);
-    if (s->n > 65536 - 32) return fail(RTK_ERR_TOO_LARGE, "rtk_set_scene: %d spheres; candidate lists index spheres with 16 bits", s->n);
+    if (s->n > (1 << 24)) return fail(RTK_ERR_TOO_LARGE, "rtk_set_scene: %d spheres exceed the limit of 2^24", s->n);
     if (!s->cx || !s->cy || !s->cz || !s->radius || !s->mat_r || !s->mat_g || !s->mat_b || !s->roughness || !s->metallic || !s->ior || !s->mat_type)
         return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null array");
     HIP_TRY(hipSetDevice(c->device));

@@ -199,11 +199,12 @@ struct Intersector {
     uint8_t* dbg_flags = nullptr;   // emulation only: [n] set to 1 for every sphere the filter passes to the exact stage
 #endif
 
-    __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int& cnt, float& closest, int& best,
+    // `list_base`: list entries are 16-bit offsets from it (the list is flushed before an offset could overflow).
+    __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int list_base, int& cnt, float& closest, int& best,
                                           uint32_t& n_exact) const {
         for (int k = 0; wave_any(k < cnt); ++k) {
             if (k < cnt) {
-                const int j = list[k * kWave + lane];
+                const int j = list_base + static_cast<int>(list[k * kWave + lane]);
                 const float4 s = exact[j];
                 float root;
                 if (sphere_root_exact(r, a, s, t_min, closest, root)) {
@@ -279,6 +280,7 @@ struct Intersector {
         float closest = t_max;
         int best = -1;
         int cnt = 0;
+        int list_base = 0;       // wave-uniform
 
         // compaction: candidate bits (MSB = first sphere of the word) -> this lane's list, ascending index;
         // when a lane's list is full the wave runs the exact stage early and carries on
@@ -293,12 +295,12 @@ struct Intersector {
                     if (cand != 0 && cnt < kListCap) {
                         const int pos = __clz(static_cast<int>(cand));
                         cand &= ~(0x80000000u >> pos);
-                        list[cnt * kWave + lane] = static_cast<uint16_t>(base + pos);
+                        list[cnt * kWave + lane] = static_cast<uint16_t>(base + pos - list_base);
                         ++cnt;
                     }
                 }
                 if (!wave_any(cand != 0)) break;
-                flush(r, a, t_min, cnt, closest, best, n_exact);
+                flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
             }
         };
         auto to_cand = [&](uint32_t m, uint32_t valid) -> uint32_t {
@@ -311,6 +313,10 @@ struct Intersector {
 
         const int full = n >> 5, rem = n & 31;
         for (int w = 0; w < full; ++w) {
+            if (w * 32 - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
+                flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                list_base = w * 32;
+            }
             uint32_t m = 0;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
@@ -329,7 +335,7 @@ struct Intersector {
             m <<= (32 - rem);
             emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
         }
-        flush(r, a, t_min, cnt, closest, best, n_exact);
+        flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         t_out = closest;
         idx_out = best;
     }

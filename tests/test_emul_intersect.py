@@ -183,3 +183,19 @@ def test_candidate_lists_overflow_path(stock_scene_golden):
     hit, idx, t, flags = e.intersect(z["degenerate_rays"], want_flags=True)
     assert (flags.sum(1) == 484).sum() > 20
     assert e.last_exact >= flags.sum()
+
+
+def test_scene_beyond_64k_spheres_rebases_the_list():
+    """BASELINE.json config 4 goes to 100k spheres: candidate lists hold 16-bit offsets that are re-based every 64k."""
+    s = rt.scaled_scene(k=135)                         # ~72.9k spheres
+    assert len(s["cx"]) > 70000
+    rng = np.random.default_rng(1)
+    m = 300
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-130, 130, m); rays[:, 1] = rng.uniform(0.01, 3, m); rays[:, 2] = rng.uniform(-130, 130, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.1
+    rays[:20, 3:6] = (np.nan, 1, 0)                    # unsafe rays: all 72.9k spheres become candidates
+    check(s, rays, noises=(0,))
+    e = Emul(s)
+    hit, idx, t = e.intersect(rays)
+    assert idx.max() > 65536                           # winners beyond the first 64k block occur
