@@ -102,9 +102,14 @@ struct RenderResult {
 };
 
 // GPU render of `world` seen by `camera`: what main.cpp:64-76 computes, as per-pixel colour sums.
-// Throws std::runtime_error with rtk_last_error() on failure (there is no CPU fallback).
-inline RenderResult render_image(const Hittable& world, const Camera& camera, int image_width, int image_height, int samples_per_pixel,
-                                 int max_depth, uint64_t seed = 0, int device = 0) {
+// The samples are rendered in `batches` progressive passes (disjoint sample indices, the per-pixel sums are
+// added on the host in fp32); `progress(samples_done, samples_total)` is called after every pass — the analogue of
+// the reference's per-scanline progress line (main.cpp:65), which has no meaning on a device that renders all
+// scanlines at once.  Throws std::runtime_error with rtk_last_error() on failure (there is no CPU fallback).
+template <class Progress>
+inline RenderResult render_image_progressive(const Hittable& world, const Camera& camera, int image_width, int image_height,
+                                             int samples_per_pixel, int max_depth, int batches, Progress&& progress, uint64_t seed = 0,
+                                             int device = 0) {
     const FlatScene flat = flatten(world);
     rtk_context* ctx = nullptr;
     const auto check = [&ctx](int status, const char* what) {
@@ -116,20 +121,47 @@ inline RenderResult render_image(const Hittable& world, const Camera& camera, in
     check(rtk_context_create(device, &ctx), "rtk_context_create");
     const rtk_scene view = flat.view();
     check(rtk_set_scene(ctx, &view), "rtk_set_scene");
-    rtk_params p{};
-    p.width = image_width;
-    p.height = image_height;
-    p.spp = samples_per_pixel;
-    p.max_depth = max_depth;
-    p.seed = seed;
-    p.t_min = 0.001f;
-    p.world_size = 1;
     const rtk_camera cam = camera.export_fields();
     RenderResult out;
-    out.rgb_sum.resize(static_cast<size_t>(image_width) * image_height * 3);
-    check(rtk_render(ctx, &cam, &p, out.rgb_sum.data(), &out.stats), "rtk_render");
+    const size_t n = static_cast<size_t>(image_width) * image_height * 3;
+    out.rgb_sum.assign(n, 0.0f);
+    std::vector<float> pass(n);
+    if (batches < 1) batches = 1;
+    if (batches > samples_per_pixel) batches = samples_per_pixel > 0 ? samples_per_pixel : 1;
+    int done = 0;
+    for (int b = 0; b < batches; ++b) {
+        const int count = (samples_per_pixel - done) / (batches - b);
+        rtk_params p{};
+        p.width = image_width;
+        p.height = image_height;
+        p.spp = count;
+        p.max_depth = max_depth;
+        p.seed = seed;
+        p.t_min = 0.001f;
+        p.world_size = 1;
+        p.sample_offset = done;
+        rtk_stats st{};
+        check(rtk_render(ctx, &cam, &p, batches == 1 ? out.rgb_sum.data() : pass.data(), &st), "rtk_render");
+        if (batches > 1)
+            for (size_t i = 0; i < n; ++i) out.rgb_sum[i] += pass[i];
+        out.stats.rays += st.rays;
+        out.stats.samples += st.samples;
+        out.stats.sphere_tests += st.sphere_tests;
+        out.stats.exact_tests += st.exact_tests;
+        out.stats.lane_slots += st.lane_slots;
+        out.stats.kernel_ms += st.kernel_ms;
+        out.stats.total_ms += st.total_ms;
+        out.stats.frames += 1;
+        done += count;
+        progress(done, samples_per_pixel);
+    }
     rtk_context_destroy(ctx);
     return out;
+}
+
+inline RenderResult render_image(const Hittable& world, const Camera& camera, int image_width, int image_height, int samples_per_pixel,
+                                 int max_depth, uint64_t seed = 0, int device = 0) {
+    return render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, 1, [](int, int) {}, seed, device);
 }
 
 } // namespace rtiow

@@ -83,6 +83,8 @@ typedef struct rtk_params {
     int32_t tile_h;
     int32_t run_len;      /* > 0: a lane sums runs of this many samples in fp32 before one fixed-point add;
                            * 0: the default decreasing partition, see rtk_run_schedule */
+    int32_t sample_offset; /* index of the first sample (default 0): a frame can be rendered progressively, in batches
+                           * [offset, offset + spp) whose sums the caller adds; batches never share RNG counters */
 } rtk_params;
 
 /* What one render did.  `rays` counts ray SEGMENTS = calls of HittableList::hit (main.cpp:90),

@@ -43,7 +43,7 @@ class rtk_camera(C.Structure):
 class rtk_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("t_min", C.c_float), ("rank", C.c_int32), ("world_size", C.c_int32),
-                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("run_len", C.c_int32)]
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("run_len", C.c_int32), ("sample_offset", C.c_int32)]
 
 
 class rtk_stats(C.Structure):
@@ -184,8 +184,8 @@ def _cam_struct(cam22) -> rtk_camera:
     return c
 
 
-def make_params(W, H, spp, depth, seed=0, t_min=0.001, rank=0, world=1, tile_w=8, tile_h=8, run_len=0) -> rtk_params:
-    return rtk_params(W, H, spp, depth, seed, t_min, rank, world, tile_w, tile_h, run_len)
+def make_params(W, H, spp, depth, seed=0, t_min=0.001, rank=0, world=1, tile_w=8, tile_h=8, run_len=0, sample_offset=0) -> rtk_params:
+    return rtk_params(W, H, spp, depth, seed, t_min, rank, world, tile_w, tile_h, run_len, sample_offset)
 
 
 class Context:
@@ -234,11 +234,11 @@ class Context:
     def synchronize(self) -> None:
         _check(self._l.rtk_synchronize(self._h), "rtk_synchronize")
 
-    def render(self, cam22, W, H, spp, depth, seed=0, t_min=0.001, tile_w=8, tile_h=8, run_len=0):
+    def render(self, cam22, W, H, spp, depth, seed=0, t_min=0.001, tile_w=8, tile_h=8, run_len=0, sample_offset=0):
         """Whole image -> (float32 [H, W, 3] colour sums, stats dict)."""
         out = np.zeros((H, W, 3), np.float32)
         st = rtk_stats()
-        p = make_params(W, H, spp, depth, seed, t_min, 0, 1, tile_w, tile_h, run_len)
+        p = make_params(W, H, spp, depth, seed, t_min, 0, 1, tile_w, tile_h, run_len, sample_offset)
         cam = _cam_struct(cam22)
         _check(self._l.rtk_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(st)), "rtk_render")
         return out, st.as_dict()

@@ -355,6 +355,7 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_render_tiles_device: call rtk_set_scene first");
     if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
     if (p->spp <= 0) return fail(RTK_ERR_BAD_ARG, "spp must be positive, got %d", p->spp);
+    if (p->sample_offset < 0 || static_cast<int64_t>(p->sample_offset) + p->spp > 0x7fffffffll) return fail(RTK_ERR_BAD_ARG, "sample_offset %d with spp %d", p->sample_offset, p->spp);
     const int world = p->world_size > 0 ? p->world_size : 1;
     if (p->rank < 0 || p->rank >= world) return fail(RTK_ERR_BAD_ARG, "rank %d of %d", p->rank, world);
     int tw, th;
@@ -398,6 +399,7 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     A.scene = c->scene;
     std::memcpy(&A.cam, cam, sizeof(float) * 22);
     A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_depth = p->max_depth;
+    A.sample_offset = static_cast<uint32_t>(p->sample_offset);
     A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
     A.t_min = p->t_min;
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;

@@ -10,6 +10,7 @@ struct RenderArgs {
     SceneDev scene;
     CameraDev cam;
     int32_t W, H, spp, max_depth;
+    uint32_t sample_offset;      // first sample index of this batch (RNG counter), rtk_params::sample_offset
     uint32_t seed_lo, seed_hi;
     float t_min;
     int32_t tile_w, tile_h, tiles_x;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 if (px < A.W && prow < A.H) {
                     pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
                     slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
-                    sample = pk_first;
+                    sample = pk_first + A.sample_offset;
                     unit_left = static_cast<int>(pk_len) - 1;
                     acc = {0, 0, 0};
                     has_unit = true;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             const V3 ud = unit_vector(ray.d);
             ++n_seg;
 #ifdef RTK_HOST_EMULATION
-            if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + sample];
+            if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + (sample - A.sample_offset)];
 #endif
             if (idx < 0) {
                 acc = acc + thr * sky_unit(ud);            // main.cpp:98-100

@@ -3,7 +3,8 @@
 // in P6 format, same progress/timing lines on stderr — with the "Image Generation" scope executed
 // on an MI355X through librtk.so instead of the CPU loops.
 //
-// Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index.
+// Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index, a 7th the number of
+// progressive passes the samples are split into (default 1; progress is reported after each pass).
 #include "MathUtils.hpp"
 
 #include "Camera.hpp"
@@ -33,6 +34,7 @@ int main(int argc, char** argv) {
     const int max_depth = argc > 4 ? static_cast<int>(std::stoll(argv[4])) : 50;
     const uint64_t seed = argc > 5 ? std::stoull(argv[5]) : 0;
     const int device = argc > 6 ? static_cast<int>(std::stoll(argv[6])) : 0;
+    const int batches = argc > 7 ? static_cast<int>(std::stoll(argv[7])) : 1;
 
     // World and camera (main.cpp:45-54)
     HittableList world = random_scene();
@@ -44,7 +46,9 @@ int main(int argc, char** argv) {
         {
             PROFILE_LOG_SCOPE("Image Generation");
             std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
-            frame = rtiow::render_image(world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device);
+            frame = rtiow::render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, batches,
+                                                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; },
+                                                    seed, device);
             rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
             std::cerr << "\rScanlines remaining: 0 \nDone.\n";
         }

@@ -134,6 +134,7 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     A.scene = e.dev;
     std::memcpy(&A.cam, cam22, 88);
     A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_depth = p->max_depth;
+    A.sample_offset = static_cast<uint32_t>(p->sample_offset);
     A.seed_lo = static_cast<uint32_t>(p->seed); A.seed_hi = static_cast<uint32_t>(p->seed >> 32);
     A.t_min = p->t_min;
     A.tile_w = tw; A.tile_h = th; A.tiles_x = tiles_x;

@@ -87,9 +87,9 @@ class Emul:
         assert rc == 0
         return out, {"rays": int(st[0]), "samples": int(st[1]), "exact_tests": int(st[2]), "passes": int(st[3])}
 
-    def render(self, cam22, W, H, spp, depth, seed=0, threads=8, run_len=0, tile_w=8, tile_h=8):
+    def render(self, cam22, W, H, spp, depth, seed=0, threads=8, run_len=0, tile_w=8, tile_h=8, sample_offset=0):
         from np_mirror import deinterleave
-        p = rt.make_params(W, H, spp, depth, seed, 0.001, 0, 1, tile_w, tile_h, run_len)
+        p = rt.make_params(W, H, spp, depth, seed, 0.001, 0, 1, tile_w, tile_h, run_len, sample_offset)
         tiles, st = self.render_tiles(cam22, p, threads)
         return deinterleave(tiles[None], W, H, 1, tile_w, tile_h), st
 

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_sizes_match_header():
     assert C.sizeof(rt.rtk_camera) == 88
     assert C.sizeof(rt.rtk_scene) == 8 + 11 * 8
-    assert C.sizeof(rt.rtk_params) == 48
+    assert C.sizeof(rt.rtk_params) == 56
     assert C.sizeof(rt.rtk_stats) == 56
 
 

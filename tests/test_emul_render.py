@@ -151,3 +151,15 @@ def test_material_none_absorbs(stock_scene_golden):
     assert st["rays"] == st["samples"]                            # every path ends at its first hit or in the sky
     out = e.scatter(np.array([[0, 5, 0, 0, -1, 0]], np.float32), np.array([481], np.int32), np.array([3.0], np.float32), np.zeros((1, 4), np.float32))
     assert out[0, 6] == 0.0
+
+
+def test_progressive_batches_cover_the_same_samples(stock_emul):
+    """rtk_params::sample_offset: two passes over [0,12) and [12,24) trace exactly the samples of one 24-sample frame
+    (same RNG counters -> same ray count; sums equal up to the fp32 rounding of the per-pass totals)."""
+    cam = rt.stock_camera(1.5)
+    full, sf = stock_emul.render(cam, 30, 20, 24, 50, seed=9, run_len=4)
+    a, sa = stock_emul.render(cam, 30, 20, 12, 50, seed=9, run_len=4, sample_offset=0)
+    b, sb = stock_emul.render(cam, 30, 20, 12, 50, seed=9, run_len=4, sample_offset=12)
+    assert sa["rays"] + sb["rays"] == sf["rays"] and sa["samples"] + sb["samples"] == sf["samples"]
+    assert np.allclose(a + b, full, rtol=2e-6, atol=1e-6)
+    assert not np.array_equal(a, b)

@@ -218,3 +218,15 @@ def test_context_reuse_and_material_none(stock_scene_golden):
     img, st = ctx.render(cam, 48, 32, 8, 50, seed=2)
     assert st["rays"] == st["samples"] and not img[-1].any() and img[0].min() > 0
     ctx.close()
+
+
+def test_progressive_batches_cover_the_same_samples(gpu_ctx):
+    """rtk_params::sample_offset (progressive rendering): two passes trace exactly the samples of one frame."""
+    cam = rt.stock_camera(1.5)
+    full, sf = gpu_ctx.render(cam, 60, 40, 24, 50, seed=9, run_len=4)
+    a, sa = gpu_ctx.render(cam, 60, 40, 12, 50, seed=9, run_len=4, sample_offset=0)
+    b, sb = gpu_ctx.render(cam, 60, 40, 12, 50, seed=9, run_len=4, sample_offset=12)
+    assert sa["rays"] + sb["rays"] == sf["rays"] and sa["samples"] + sb["samples"] == sf["samples"]
+    assert np.allclose(a + b, full, rtol=2e-6, atol=1e-6) and not np.array_equal(a, b)
+    with pytest.raises(rt.RtkError, match="sample_offset"):
+        gpu_ctx.render(cam, 16, 16, 4, 1, sample_offset=-1)
