@@ -34,6 +34,8 @@ struct RenderArgs {
 // at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
 // run in fp32 and adds the run total once, as 32.32 fixed point, to the pixel's accumulator: integer
 // adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
+constexpr int kDequeue = 2;      // packets a wavefront draws from the queue per atomic
+
 template <bool LDS>
 __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect) {
     const int lane = isect.lane;
@@ -49,7 +51,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
     // wave state (uniform)
     int pk_pos = kTilePixels, pk_lt = 0, pk_x0 = 0, pk_y0 = 0;
-    uint32_t pk_first = 0, pk_len = 1;
+    uint32_t pk_first = 0, pk_len = 1, pk_next = 0, pk_end = 0;
     bool queue_empty = false;
     uint32_t wave_passes = 0;
 
@@ -83,14 +85,21 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             const uint64_t nb = ballot(need);
             if (nb == 0ull) break;
             if (pk_pos >= kTilePixels) {
-                if (queue_empty) break;
-                uint32_t q = 0;
-                if (lane == 0) q = atomicAdd(A.queue, 1u);
-                q = __builtin_amdgcn_readfirstlane(q);
-                if (q >= A.total_packets) {
-                    queue_empty = true;
-                    break;
+                if (pk_next >= pk_end) {
+                    // draw kDequeue consecutive packets at once: towards the end of a frame the runs are single
+                    // samples, and one packet per draw would push the shared counter towards its saturation rate
+                    if (queue_empty) break;
+                    uint32_t q0 = 0;
+                    if (lane == 0) q0 = atomicAdd(A.queue, static_cast<uint32_t>(kDequeue));
+                    q0 = __builtin_amdgcn_readfirstlane(q0);
+                    if (q0 >= A.total_packets) {
+                        queue_empty = true;
+                        break;
+                    }
+                    pk_next = q0;
+                    pk_end = (A.total_packets - q0 < static_cast<uint32_t>(kDequeue)) ? A.total_packets : q0 + kDequeue;
                 }
+                const uint32_t q = pk_next++;
                 // per-packet (wave-uniform) quantities: run of samples, tile origin
                 const uint2 run = A.runs[q / static_cast<uint32_t>(A.n_local_tiles)];
                 pk_first = run.x;

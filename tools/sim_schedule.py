@@ -28,7 +28,7 @@ def path_lengths():
     return seg
 
 
-def simulate(seg, W, H, spp, n_gpus, runs, waves_per_gpu=6144, up=4, seed=0):
+def simulate(seg, W, H, spp, n_gpus, runs, waves_per_gpu=6144, up=4, seed=0, dequeue=2):
     """Time-stepped (one wave pass per step, all waves in lockstep = equal speed) model of rank 0's kernel.
     seg: [h*w, S] path lengths at low resolution; the frame is W x H = up x the low resolution."""
     rng = np.random.default_rng(seed)
@@ -51,6 +51,7 @@ def simulate(seg, W, H, spp, n_gpus, runs, waves_per_gpu=6144, up=4, seed=0):
     rem = np.zeros((nw, 64), np.int32)
     pk = np.zeros(nw, np.int64)
     pos = np.full(nw, 64, np.int64)
+    pend = np.zeros(nw, np.int64)                              # packets already drawn but not started (batched dequeue)
     next_packet = 0
     passes = np.zeros(nw, np.int64)
     busy_lane_passes = 0
@@ -58,7 +59,7 @@ def simulate(seg, W, H, spp, n_gpus, runs, waves_per_gpu=6144, up=4, seed=0):
     while True:
         free = rem == 0
         need = free.sum(1)
-        if need.any() and (next_packet < n_packets or (pos < 64).any()):
+        if need.any() and (next_packet < n_packets or (pos < 64).any() or (pend > 0).any()):
             rank = np.cumsum(free, 1) - 1                         # rank of each free lane among the wave's free lanes
             avail = 64 - pos
             # part 1: from the current packet
@@ -71,11 +72,22 @@ def simulate(seg, W, H, spp, n_gpus, runs, waves_per_gpu=6144, up=4, seed=0):
             # part 2: waves that still need units draw a new packet, in wave order
             more = need - took1
             wants = (more > 0)
-            nwant = int(wants.sum())
-            if nwant and next_packet < n_packets:
-                ids = next_packet + np.cumsum(wants) - 1
-                ok = wants & (ids < n_packets)
-                next_packet = min(n_packets, next_packet + nwant)
+            # waves with a pending (already drawn) packet start it; the others draw `dequeue` packets, in wave order
+            have = wants & (pend > 0)
+            draw = wants & ~have & (next_packet < n_packets)
+            ids = np.where(have, pk + 1, 0)
+            nd = int(draw.sum())
+            if nd:
+                first = next_packet + (np.cumsum(draw) - 1) * dequeue
+                ok_draw = draw & (first < n_packets)
+                got = np.minimum(dequeue, n_packets - first)
+                ids = np.where(ok_draw, first, ids)
+                pend = np.where(ok_draw, got, pend)
+                next_packet = min(n_packets, next_packet + nd * dequeue)
+                have = have | ok_draw
+            ok = have
+            if ok.any():
+                pend = np.where(ok, pend - 1, pend)
                 pk = np.where(ok, ids, pk)
                 pos = np.where(ok, 0, pos)
                 t2 = free & ~t1 & ok[:, None]
