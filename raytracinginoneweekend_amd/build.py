@@ -27,7 +27,7 @@ def _stale(target: str, sources) -> bool:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, "rtk.hip")]
-    deps = srcs + [os.path.join(CSRC, "rtk_device.hpp"), os.path.join(ROOT, "include", "rtk.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rtk.h")]   # every header counts
     if force or _stale(LIB, deps):
         cmd = [HIPCC, *HIP_FLAGS, "-shared", "-I", os.path.join(ROOT, "include"), *srcs, "-o", LIB]
         if verbose:
@@ -42,7 +42,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(hdir, "main.cpp")
     if not os.path.exists(src):
         return ""
-    deps = [src] + [os.path.join(ROOT, "include", "rtiow", f) for f in os.listdir(os.path.join(ROOT, "include", "rtiow"))]
+    deps = [src, os.path.join(ROOT, "include", "rtk.h")] + [os.path.join(ROOT, "include", "rtiow", f) for f in os.listdir(os.path.join(ROOT, "include", "rtiow"))]
     if force or _stale(HOST_BIN, deps + [LIB]):
         cmd = ["g++", "-std=c++20", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I",
                os.path.join(ROOT, "include", "rtiow"), src, "-o", HOST_BIN, "-L", HERE, "-lrtk", f"-Wl,-rpath,{HERE}",
@@ -57,7 +57,7 @@ def build_host_capi(force: bool = False, verbose: bool = False) -> str:
     """C view of the C++ host scene API for Python (tests, bench.py): librtiow_host.so.  CPU only."""
     src = os.path.join(HERE, "host", "host_capi.cpp")
     inc = os.path.join(ROOT, "include", "rtiow")
-    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    deps = [src, os.path.join(ROOT, "include", "rtk.h")] + [os.path.join(inc, f) for f in os.listdir(inc)]
     if force or _stale(HOST_CAPI, deps):
         cmd = ["g++", "-std=c++20", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I", inc,
                src, "-o", HOST_CAPI]

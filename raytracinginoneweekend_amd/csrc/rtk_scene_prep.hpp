@@ -88,7 +88,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out) {
 // The partition of a pixel's `spp` samples into runs (a lane sums one run in fp32, then adds it to the pixel's
 // integer accumulator).  It depends on spp and the image size ONLY, never on the GPU count or the scheduling, so
 // images stay bit-identical across ranks.  run_len > 0: equal runs of that length.  run_len == 0 (default):
-// decreasing runs, L = max(1, remaining / k): units are large while there is plenty of work and shrink towards
+// decreasing runs, L = ceil(remaining / k): units are large while there is plenty of work and shrink towards
 // the end of the frame, so that no lane is still inside a long unit when the packet queue runs dry (the tail
 // sets the kernel's end; hot pixels — glass interiors — cost up to 7x the mean per sample).  k grows as the
 // frame shrinks (fewer pixels per lane -> the tail matters more): k = clamp(66.7e6 / (W*H), 8, 64), sized for
@@ -105,7 +105,7 @@ inline std::vector<uint2> run_schedule(int spp, int width, int height, int run_l
     int s = 0;
     while (s < spp) {
         const int rem = spp - s;
-        const int len = std::max(1, rem / k);
+        const int len = (rem + k - 1) / k;          // >= 1
         runs.push_back(make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(len)));
         s += len;
     }

@@ -71,7 +71,8 @@ def test_run_schedule_partitions_the_samples():
             assert r[-1, 1] == 1 or spp < 8                            # the frame ends on single-sample units
         else:
             assert (r[:-1, 1] == min(rl, spp)).all()
-    # C2: k = 64 -> first run 7 samples, about 200 runs; C3: k = 9 -> first run 111 samples
-    assert rt.run_schedule(500, 1200, 800)[0, 1] == 7 and 150 < len(rt.run_schedule(500, 1200, 800)) < 260
-    assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 111
+    # C2: k = 64 -> first run 8 samples, 172 runs, the last 64 samples one by one; C3: k = 9 -> first run 112 samples
+    c2 = rt.run_schedule(500, 1200, 800)
+    assert c2[0, 1] == 8 and len(c2) == 172 and (c2[:, 1] == 1).sum() == 64
+    assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 112
     assert rt.lib().rtk_run_schedule(0, 10, 10, 0, None, 0) == -1
