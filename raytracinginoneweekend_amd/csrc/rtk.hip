@@ -227,6 +227,8 @@ int rtk_device_count(void) {
 
 const char* rtk_last_error(void) { return g_err; }
 
+void rtk_context_destroy(rtk_context* c);
+
 int rtk_context_create(int device, rtk_context** out) {
     if (!out) return fail(RTK_ERR_BAD_ARG, "rtk_context_create: out is null");
     *out = nullptr;
@@ -237,20 +239,26 @@ int rtk_context_create(int device, rtk_context** out) {
     rtk_context* c = new (std::nothrow) rtk_context();
     if (!c) return fail(RTK_ERR_HIP, "out of host memory");
     c->device = device;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        delete c;
-        return fail(RTK_ERR_NO_DEVICE, "device %d is %s; librtk is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    // everything below goes through init(): on any failure the half-built context is destroyed, nothing leaks
+    const auto init = [c, device]() -> int {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(RTK_ERR_NO_DEVICE, "device %d is %s; librtk is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        c->n_cu = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev3));
+        for (hipEvent_t& e : c->kev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(c->control.reserve(512));
+        HIP_TRY(hipMemset(c->control.p, 0, 512));
+        return RTK_OK;
+    };
+    if (const int e = init()) {
+        rtk_context_destroy(c);
+        return e;
     }
-    c->n_cu = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev3));
-    for (hipEvent_t& e : c->kev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(c->control.reserve(512));
-    HIP_TRY(hipMemset(c->control.p, 0, 512));
     *out = c;
     return RTK_OK;
 }

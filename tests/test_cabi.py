@@ -76,3 +76,12 @@ def test_run_schedule_partitions_the_samples():
     assert c2[0, 1] == 8 and len(c2) == 172 and (c2[:, 1] == 1).sum() == 64
     assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 112
     assert rt.lib().rtk_run_schedule(0, 10, 10, 0, None, 0) == -1
+
+
+def test_built_library_is_not_older_than_its_sources():
+    """The GPU box runs the in-tree librtk.so as it is (no build there): it must be newer than every kernel source."""
+    csrc = os.path.join(ROOT, "raytracinginoneweekend_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, "include", "rtk.h")]
+    lib_time = os.path.getmtime(rt.LIB_PATH)
+    stale = [os.path.basename(s) for s in srcs if os.path.getmtime(s) > lib_time]
+    assert not stale, "rebuild librtk.so (python -m raytracinginoneweekend_amd.build): newer sources %s" % stale
