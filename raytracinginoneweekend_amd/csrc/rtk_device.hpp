@@ -18,6 +18,11 @@
 #endif
 #include <stdint.h>
 
+#ifndef RTK_HOST_EMULATION
+#define RTK_STAT(lane, name) ((void)0)
+#define RTK_STAT_ANY(lane, name, pred) ((void)0)
+#endif
+
 #ifndef RTK_LANES
 #define RTK_LANES 64
 #endif
@@ -203,6 +208,7 @@ struct Intersector {
     __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int list_base, int& cnt, float& closest, int& best,
                                           uint32_t& n_exact) const {
         for (int k = 0; wave_any(k < cnt); ++k) {
+            RTK_STAT(lane, flush_iters);
             if (k < cnt) {
                 const int j = list_base + static_cast<int>(list[k * kWave + lane]);
                 const float4 s = exact[j];
@@ -277,6 +283,7 @@ struct Intersector {
             f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
         }
 #endif
+        RTK_STAT(lane, closest_hit_calls);
         float closest = t_max;
         int best = -1;
         int cnt = 0;
@@ -292,6 +299,7 @@ struct Intersector {
 #endif
             for (;;) {
                 while (wave_any(cand != 0 && cnt < kListCap)) {
+                    RTK_STAT(lane, compact_iters);
                     if (cand != 0 && cnt < kListCap) {
                         const int pos = __clz(static_cast<int>(cand));
                         cand &= ~(0x80000000u >> pos);
@@ -300,6 +308,7 @@ struct Intersector {
                     }
                 }
                 if (!wave_any(cand != 0)) break;
+                RTK_STAT(lane, early_flushes);
                 flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
             }
         };
@@ -323,6 +332,7 @@ struct Intersector {
                 const auto s = RTK_FILT_LOAD(w * 32 + i);
                 filter_one(f, s.x, s.y, s.z, s.w, m);
             }
+            RTK_STAT(lane, filter_words);
             emit(w * 32, to_cand(m, 0xFFFFFFFFu));
         }
         if (rem) {

@@ -58,6 +58,8 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     for (;;) {
         // ---- lanes without a live path: next sample of the unit, or retire the unit ----
         bool start = false, need = false;
+        RTK_STAT_ANY(lane, pass_refill_block, !alive);
+        RTK_STAT_ANY(lane, pass_unit_flush_block, !alive && has_unit && unit_left <= 0);
         if (!alive) {
             if (has_unit && unit_left > 0) {
                 --unit_left;
@@ -84,6 +86,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         for (;;) {
             const uint64_t nb = ballot(need);
             if (nb == 0ull) break;
+            RTK_STAT(lane, pass_assign_iters);
             if (pk_pos >= kTilePixels) {
                 if (pk_next >= pk_end) {
                     // draw kDequeue consecutive packets at once: towards the end of a frame the runs are single
@@ -100,6 +103,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                     pk_end = (A.total_packets - q0 < static_cast<uint32_t>(kDequeue)) ? A.total_packets : q0 + kDequeue;
                 }
                 const uint32_t q = pk_next++;
+                RTK_STAT(lane, packet_draws);
                 // per-packet (wave-uniform) quantities: run of samples, tile origin
                 const uint2 run = A.runs[q / static_cast<uint32_t>(A.n_local_tiles)];
                 pk_first = run.x;
@@ -132,6 +136,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             pk_pos += took < avail ? took : avail;
         }
         // ---- primary rays (main.cpp:69-71) ----
+        RTK_STAT_ANY(lane, pass_start_block, start);
         if (start) {
             const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
             const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
@@ -151,6 +156,16 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         int idx;
         isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
         ++wave_passes;
+        RTK_STAT_ANY(lane, pass_sky_block, alive && idx < 0);
+        RTK_STAT_ANY(lane, pass_hit_block, alive && idx >= 0);
+#ifdef RTK_HOST_EMULATION
+        {
+            const int ty_ = (alive && idx >= 0) ? __float_as_int(A.scene.mat1[idx].z) : 0;
+            RTK_STAT_ANY(lane, pass_lambert, ty_ == 1);
+            RTK_STAT_ANY(lane, pass_metal, ty_ == 2);
+            RTK_STAT_ANY(lane, pass_glass, ty_ == 3);
+        }
+#endif
         if (alive) {
             // unit_vector(r.direction()) of main.cpp:98 / Material.cpp:22,36 — one evaluation serves sky, metal and glass
             const V3 ud = unit_vector(ray.d);

@@ -10,9 +10,37 @@
 #include <thread>
 #include <vector>
 
+#include <mutex>
+
 namespace rtk_shim {
 thread_local int ulp_noise = 0;
 thread_local uint32_t noise_state = 12345u;
+thread_local WaveStats wave_stats = {};
+}
+
+// Statistics of all emulated waves since the last emul_reset_stats (every OS thread folds its own in).
+static rtk_shim::WaveStats g_stats = {};
+static std::mutex g_stats_mutex;
+static bool g_simt_error = false;
+static void fold_stats() {
+    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    auto* dst = reinterpret_cast<unsigned long long*>(&g_stats);
+    auto* src = reinterpret_cast<unsigned long long*>(&rtk_shim::wave_stats);
+    for (size_t i = 0; i < sizeof(g_stats) / sizeof(unsigned long long); ++i) dst[i] += src[i];
+    rtk_shim::wave_stats = {};
+}
+
+// Runs body(lane) for every lane of one wavefront on the calling thread: 64 fibers meeting at the votes
+// (RTK_LANES == 64, rtk_simt.hpp) or a single lane (RTK_LANES == 1).
+template <class F>
+static void run_lanes(F&& body) {
+#if RTK_LANES == 64
+    rtk_simt::Wave* w = new rtk_simt::Wave();
+    if (!rtk_simt::run_wave(*w, body)) g_simt_error = true;
+    delete w;
+#else
+    body(0);
+#endif
 }
 
 using namespace rtk;
@@ -22,7 +50,7 @@ struct Emul {
     SceneDev dev;
 };
 
-static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg) {
+static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0) {
     Intersector<false> it;
     it.filt = e.ps.filt.data();
     it.filt_global = e.ps.filt.data();
@@ -30,7 +58,7 @@ static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg
     it.list = list;
     it.fb = e.ps.fb;
     it.n = e.ps.n;
-    it.lane = 0;
+    it.lane = lane;
     it.dbg_flags = dbg;
     return it;
 }
@@ -59,21 +87,33 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
                     uint64_t* n_exact_total, int ulp_noise) {
     const Emul& e = *static_cast<Emul*>(h);
     rtk_shim::ulp_noise = ulp_noise;
-    uint16_t list[kListCap * kWave];
+    std::vector<uint16_t> list(kListCap * kWave);
+    std::vector<uint32_t> ne_lane(kWave, 0);
     uint64_t total = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const Intersector<false> it = make_isect(e, list, flags ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr);
-        const float* q = rays + 6 * i;
-        const Ray r = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
-        float tt;
-        int idx;
-        uint32_t ne = 0;
-        it.closest_hit(r, true, t_min, t_max, tt, idx, ne);
-        total += ne;
-        hit[i] = idx >= 0;
-        index[i] = idx;
-        t[i] = idx >= 0 ? tt : 0.0f;
+    for (uint64_t base = 0; base < n; base += kWave) {
+        run_lanes([&](int lane) {
+            const uint64_t i = base + static_cast<uint64_t>(lane);
+            const bool active = i < n;
+            const Intersector<false> it = make_isect(e, list.data(), (flags && active) ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr, lane);
+            Ray r = {};
+            if (active) {
+                const float* q = rays + 6 * i;
+                r = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+            }
+            float tt;
+            int idx;
+            uint32_t ne = 0;
+            it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
+            ne_lane[lane] = ne;
+            if (active) {
+                hit[i] = idx >= 0;
+                index[i] = idx;
+                t[i] = idx >= 0 ? tt : 0.0f;
+            }
+        });
+        for (int l = 0; l < kWave; ++l) { total += ne_lane[l]; ne_lane[l] = 0; }
     }
+    fold_stats();
     if (n_exact_total) *n_exact_total = total;
     rtk_shim::ulp_noise = 0;
 }
@@ -151,14 +191,31 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     std::vector<std::thread> pool;
     for (int k = 0; k < threads; ++k)
         pool.emplace_back([&] {
-            uint16_t list[kListCap * kWave];
-            const Intersector<false> it = make_isect(e, list, nullptr);
-            render_wave<false>(A, it);
+            std::vector<uint16_t> list(kListCap * kWave);
+            run_lanes([&](int lane) {
+                const Intersector<false> it = make_isect(e, list.data(), nullptr, lane);
+                render_wave<false>(A, it);
+            });
+            fold_stats();
         });
     for (auto& t : pool) t.join();
     for (size_t i = 0; i < accum.size(); ++i) tile_sums[i] = accum_to_float(accum[i]);
     for (int i = 0; i < 4; ++i) stats4[i] = stats[i];
     return 0;
 }
+
+// wave-level statistics (rtk_shim::WaveStats as an array of u64) since the last reset; returns the lane count of the build
+int emul_get_stats(unsigned long long* out, int cap) {
+    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    const int n = static_cast<int>(sizeof(g_stats) / sizeof(unsigned long long));
+    const auto* src = reinterpret_cast<const unsigned long long*>(&g_stats);
+    for (int i = 0; i < n && i < cap; ++i) out[i] = src[i];
+    return kWave;
+}
+void emul_reset_stats() {
+    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    g_stats = {};
+}
+int emul_simt_error() { return g_simt_error ? 1 : 0; }
 
 } // extern "C"

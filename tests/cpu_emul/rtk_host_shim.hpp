@@ -32,7 +32,12 @@ inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); r
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline long long __double2ll_rn(double d) { return std::llrint(d); }
+#if defined(RTK_LANES) && RTK_LANES == 64
+#include "rtk_simt.hpp"
+inline unsigned long long __ballot(bool p) { return rtk_simt::ballot(p); }
+#else
 inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+#endif
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
@@ -66,6 +71,26 @@ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return static_
 #define __builtin_amdgcn_exp2f(x) rtk_shim::exp2f_(x)
 #define __builtin_amdgcn_logf(x) rtk_shim::log2f_(x)
 #define __builtin_amdgcn_alignbit(a, b, c) rtk_shim::alignbit(a, b, c)
+#if defined(RTK_LANES) && RTK_LANES == 64
+#define __builtin_amdgcn_mbcnt_lo(m, v) rtk_simt::mbcnt_lo(m, v)
+#define __builtin_amdgcn_mbcnt_hi(m, v) rtk_simt::mbcnt_hi(m, v)
+#define __builtin_amdgcn_readfirstlane(x) rtk_simt::readfirstlane(x)
+#else
 #define __builtin_amdgcn_mbcnt_lo(m, v) (v)
 #define __builtin_amdgcn_mbcnt_hi(m, v) (v)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#endif
+
+// Dynamic wave-level statistics of the emulated kernels (how often each block of the pass executes for a wave).
+namespace rtk_shim {
+struct WaveStats {
+    unsigned long long closest_hit_calls, filter_words, compact_iters, early_flushes, flush_iters;
+    unsigned long long pass_refill_block, pass_assign_iters, pass_start_block, pass_sky_block, pass_hit_block;
+    unsigned long long pass_lambert, pass_metal, pass_glass, pass_unit_flush_block, packet_draws;
+};
+extern thread_local WaveStats wave_stats;
+}
+// counted once per wave (by lane 0 of it)
+#define RTK_STAT(lane, name) do { if ((lane) == 0) ++rtk_shim::wave_stats.name; } while (0)
+// counted once per wave when ANY lane satisfies `pred` (an extra vote that exists only in the emulation build)
+#define RTK_STAT_ANY(lane, name, pred) do { const bool any_ = __ballot(pred) != 0ull; if (any_ && (lane) == 0) ++rtk_shim::wave_stats.name; } while (0)

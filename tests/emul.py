@@ -9,15 +9,18 @@ import numpy as np
 import raytracinginoneweekend_amd as rt
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "cpu_emul", "libemul.so")
-_lib = None
+_libs = {}
+
+STAT_FIELDS = ("closest_hit_calls", "filter_words", "compact_iters", "early_flushes", "flush_iters", "pass_refill_block",
+               "pass_assign_iters", "pass_start_block", "pass_sky_block", "pass_hit_block", "pass_lambert", "pass_metal",
+               "pass_glass", "pass_unit_flush_block", "packet_draws")
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(lanes=1):
+    """lanes = 1: one lane per wave (fast).  lanes = 64: 64 fibers per wave meeting at the votes (cross-lane logic)."""
+    if lanes not in _libs:
         subprocess.run(["make", "-C", os.path.join(HERE, "cpu_emul")], check=True, capture_output=True)
-        l = C.CDLL(LIB)
+        l = C.CDLL(os.path.join(HERE, "cpu_emul", "libemul.so" if lanes == 1 else "libemul64.so"))
         vp = C.c_void_p
         l.emul_create.restype = vp
         l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]
@@ -28,13 +31,25 @@ def lib():
         l.emul_primary.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, vp, C.c_uint64, vp]
         l.emul_philox.argtypes = [C.c_uint64, vp, C.c_uint64, vp]
         l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int, vp]
-        _lib = l
-    return _lib
+        l.emul_get_stats.argtypes = [vp, C.c_int]
+        _libs[lanes] = l
+    return _libs[lanes]
+
+
+def wave_stats(lanes=1, reset=True):
+    """Wave-level block execution counts of the emulated kernels since the last reset."""
+    out = np.zeros(len(STAT_FIELDS), np.uint64)
+    got = lib(lanes).emul_get_stats(out.ctypes.data, len(out))
+    assert got == lanes
+    if reset:
+        lib(lanes).emul_reset_stats()
+    return dict(zip(STAT_FIELDS, (int(x) for x in out)))
 
 
 class Emul:
-    def __init__(self, scene: dict):
-        self._l = lib()
+    def __init__(self, scene: dict, lanes: int = 1):
+        self._l = lib(lanes)
+        self.lanes = lanes
         arrs = {k: np.ascontiguousarray(scene[k], np.float32) for k in rt.SCENE_FIELDS[:10]}
         arrs["mat_type"] = np.ascontiguousarray(scene["mat_type"], np.int32)
         s = rt.rtk_scene()
