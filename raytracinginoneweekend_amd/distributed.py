@@ -32,25 +32,42 @@ def gather_tiles(local_tiles: torch.Tensor, group=None) -> torch.Tensor:
 
 
 class ShardedRenderer:
-    """Persistent per-rank state: context, tile buffer, gathered buffer, image."""
+    """Persistent per-rank state: context, tile buffer, gathered buffer, image.
+
+    All GPU work of a frame — render kernel, finalise, all_gather, de-interleave — is queued on ONE torch stream
+    (`self.stream`, a non-default stream whose handle is given to the context): the collective is issued under
+    `torch.cuda.stream(self.stream)`, so RCCL orders it after the kernels that fill the tile buffer and before the
+    kernel that reads the gathered one.  (torch's default stream has handle 0, which rtk_context_set_stream
+    reads as "use the context's own stream": work on it would NOT be ordered against torch's collectives.)
+    """
 
     def __init__(self, ctx: Context, W: int, H: int, rank: int, world: int, device: torch.device, tile_w: int = 8, tile_h: int = 8):
         self.ctx, self.W, self.H, self.rank, self.world = ctx, W, H, rank, world
         self.tile_w, self.tile_h = tile_w, tile_h
+        self.device = device
         self.tprp = tiles_per_rank_padded(W, H, world, tile_w, tile_h)
         self.local = torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.float32, device=device)
         self.image = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
-        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.stream = torch.cuda.Stream(device=device)
+        self.stream.wait_stream(torch.cuda.current_stream(device))     # the zero-fills above
+        assert self.stream.cuda_stream != 0
+        ctx.set_stream(self.stream.cuda_stream)
+        self._keep = None
 
     def params(self, spp: int, depth: int, seed: int = 0, run_len: int = 0):
         return make_params(self.W, self.H, spp, depth, seed, 0.001, self.rank, self.world, self.tile_w, self.tile_h, run_len)
 
     def render(self, cam22, spp: int, depth: int, seed: int = 0, want_stats: bool = False, assemble: bool = True):
-        """Render this rank's tiles, gather, de-interleave.  Returns stats (or None); the image is self.image."""
+        """Render this rank's tiles, gather, de-interleave (asynchronous on self.stream).  Returns stats (or None);
+        the image is self.image once self.stream has been synchronised."""
         p = self.params(spp, depth, seed)
-        st = self.ctx.render_tiles_device(cam22, p, self.local.data_ptr(), want_stats)
-        if assemble:
-            gathered = gather_tiles(self.local)
-            self.ctx.deinterleave_device(gathered.data_ptr(), self.tprp, p, self.image.data_ptr())
-            self._keep = gathered   # alive until the kernel that reads it has been queued behind it
+        with torch.cuda.stream(self.stream):
+            st = self.ctx.render_tiles_device(cam22, p, self.local.data_ptr(), want_stats)
+            if assemble:
+                gathered = gather_tiles(self.local)
+                self.ctx.deinterleave_device(gathered.data_ptr(), self.tprp, p, self.image.data_ptr())
+                self._keep = gathered   # keep the buffer alive until the next frame has been queued behind this one
         return st
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()

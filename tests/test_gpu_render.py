@@ -230,3 +230,21 @@ def test_progressive_batches_cover_the_same_samples(gpu_ctx):
     assert np.allclose(a + b, full, rtol=2e-6, atol=1e-6) and not np.array_equal(a, b)
     with pytest.raises(rt.RtkError, match="sample_offset"):
         gpu_ctx.render(cam, 16, 16, 4, 1, sample_offset=-1)
+
+
+def test_sharded_renderer_single_rank_matches_rtk_render(stock_scene_golden):
+    """bench.py's path (ShardedRenderer on its own torch stream: tiles -> gather -> de-interleave) at world size 1."""
+    import torch
+    from raytracinginoneweekend_amd.distributed import ShardedRenderer
+    ctx = rt.Context(0)
+    ctx.set_scene(stock_scene_golden)
+    W, H = 100, 60
+    cam = rt.stock_camera(W / H)
+    ref, st = ctx.render(cam, W, H, 16, 50, seed=4)
+    sr = ShardedRenderer(ctx, W, H, 0, 1, torch.device("cuda", 0))
+    for _ in range(2):                                       # twice: the accumulators must come back zeroed
+        sr.render(cam, 16, 50, seed=4)
+        sr.synchronize()
+        assert np.array_equal(bits(sr.image.cpu().numpy()), bits(ref))
+    ctx.set_stream(0)
+    ctx.close()
