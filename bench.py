@@ -171,6 +171,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    # tear down in order: the context must not outlive the torch stream it was pointed at
+    torch.cuda.synchronize()
+    ctx.set_stream(0)
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
