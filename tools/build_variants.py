@@ -1,0 +1,24 @@
+"""Build A/B variants of librtk.so into raytracinginoneweekend_amd/variants/ (git-ignored, travels with gpurun) for
+tools/ab_bench.py.  Each variant is the shipped source with extra -D flags.  REVIEW a variant's memory accesses
+before running it on a GPU: a faulting kernel closes GPU access for the round (it happened in round 1).
+
+    python tools/build_variants.py            # builds the set below
+    gpurun -- 'python tools/ab_bench.py 100 2'
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracinginoneweekend_amd", "csrc")
+OUT = os.path.join(ROOT, "raytracinginoneweekend_amd", "variants")
+BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include")]
+VARIANTS = {
+    "ship": [],                                    # projection filter, LDS broadcast operands
+    "form0": ["-DRTK_FILTER_FORM=0"],              # discriminant filter (11 VALU / test)
+    "smem": ["-DRTK_SMEM=1"],                      # filter operands by scalar loads from the GLOBAL copy (SGPR operands)
+}
+os.makedirs(OUT, exist_ok=True)
+for name, flags in VARIANTS.items():
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        continue
+    out = os.path.join(OUT, f"librtk_{name}.so")
+    subprocess.run(BASE + flags + [os.path.join(CSRC, "rtk.hip"), "-o", out], check=True)
+    print("built", out)
