@@ -199,3 +199,12 @@ def test_scene_beyond_64k_spheres_rebases_the_list():
     e = Emul(s)
     hit, idx, t = e.intersect(rays)
     assert idx.max() > 65536                           # winners beyond the first 64k block occur
+
+
+@pytest.mark.parametrize("t_min,t_max", [(0.0, np.inf), (-5.0, 3.0), (2.0, 1.0), (0.001, np.nan), (np.nan, np.inf), (-np.inf, np.inf), (1e-30, 1e30)])
+def test_unusual_ranges(stock_scene_golden, t_min, t_max):
+    """Sphere3::hit's range tests are plain comparisons (false for NaN): negative, empty, infinite and NaN ranges
+    must behave as in the reference."""
+    z = load_golden("rays_stock.npz")
+    rays = np.concatenate([z["primary_rays"][:1500], z["inside_rays"][:800], z["degenerate_rays"]])
+    check(stock_scene_golden, rays, t_min, t_max, noises=(0,))

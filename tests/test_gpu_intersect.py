@@ -156,3 +156,10 @@ def test_scene_beyond_64k_spheres():
     check(got, *o.intersect(rays))
     assert got[1].max() > 65536
     ctx.close()
+
+
+@pytest.mark.parametrize("t_min,t_max", [(0.0, np.inf), (-5.0, 3.0), (2.0, 1.0), (0.001, np.nan), (np.nan, np.inf), (-np.inf, np.inf)])
+def test_unusual_ranges(gpu_ctx, oracle_stock, t_min, t_max):
+    z = load_golden("rays_stock.npz")
+    rays = np.concatenate([z["primary_rays"][:1500], z["inside_rays"][:800], z["degenerate_rays"]])
+    check(gpu_ctx.intersect(rays, t_min, t_max), *oracle_stock.intersect(rays, t_min, t_max))
