@@ -1,5 +1,5 @@
-// rtiow/Camera.hpp — thin-lens camera (reference: Camera.hpp:6-40), plus export_fields() so the eight
-// private fields can cross the C ABI.
+// rtiow/Camera.hpp — thin-lens camera with the reference's constructor and get_ray() (reference: Camera.hpp:6-40).
+// The precomputed frame is kept directly in the C ABI's rtk_camera record, so handing it to the GPU is a copy.
 #pragma once
 
 #include "Ray3.hpp"
@@ -11,43 +11,45 @@
 class Camera {
 public:
     Camera(Point3 lookFrom, Point3 lookAt, Vector3 vUp, float vfovDegrees, float aspectRatio, float aperture, float focusDistance) {
+        // viewport size from the vertical field of view
         const float half_height = std::tan(degrees_to_radians(vfovDegrees) * 0.5f);
-        const float viewport_height = 2.0f * half_height;
-        const float viewport_width = aspectRatio * viewport_height;
-        w = unit_vector(lookFrom - lookAt);
-        u = unit_vector(cross(vUp, w));
-        v = cross(w, u);
-        origin = lookFrom;
-        horizontal = focusDistance * viewport_width * u;
-        vertical = focusDistance * viewport_height * v;
-        lower_left_corner = origin - horizontal * 0.5f - vertical * 0.5f - focusDistance * w;
-        lens_radius = aperture * 0.5f;
+        const float view_h = 2.0f * half_height;
+        const float view_w = aspectRatio * view_h;
+        // right-handed frame: w points from the target to the eye
+        const Vector3 back = unit_vector(lookFrom - lookAt);
+        const Vector3 right = unit_vector(cross(vUp, back));
+        const Vector3 up = cross(back, right);
+        const Vector3 across = focusDistance * view_w * right;
+        const Vector3 upward = focusDistance * view_h * up;
+        const Point3 corner = lookFrom - across * 0.5f - upward * 0.5f - focusDistance * back;
+        store(frame_.origin, lookFrom);
+        store(frame_.lower_left_corner, corner);
+        store(frame_.horizontal, across);
+        store(frame_.vertical, upward);
+        store(frame_.u, right);
+        store(frame_.v, up);
+        store(frame_.w, back);
+        frame_.lens_radius = aperture * 0.5f;
     }
 
+    // Ray through viewport coordinates (s, t) from a random point of the lens disk (stream G1).
     Ray3 get_ray(float s, float t) const {
-        const Vector3 rd = lens_radius * random_in_unit_disk();
-        const Vector3 offset = u * rd.x() + v * rd.y();
-        return Ray3{origin + offset, lower_left_corner + s * horizontal + t * vertical - origin - offset};
+        const Vector3 lens = frame_.lens_radius * random_in_unit_disk();
+        const Vector3 shift = load(frame_.u) * lens.x() + load(frame_.v) * lens.y();
+        const Point3 eye = load(frame_.origin);
+        return Ray3{eye + shift, load(frame_.lower_left_corner) + s * load(frame_.horizontal) + t * load(frame_.vertical) - eye - shift};
     }
 
     // Not in the reference: the precomputed fields, for rtk_render.
-    rtk_camera export_fields() const {
-        rtk_camera c;
-        const Vector3* src[7] = {&origin, &lower_left_corner, &horizontal, &vertical, &u, &v, &w};
-        float* dst[7] = {c.origin, c.lower_left_corner, c.horizontal, c.vertical, c.u, c.v, c.w};
-        for (int i = 0; i < 7; ++i)
-            for (int k = 0; k < 3; ++k) dst[i][k] = (*src[i])[k];
-        c.lens_radius = lens_radius;
-        return c;
-    }
+    rtk_camera export_fields() const { return frame_; }
 
 private:
-    Point3 origin;
-    Point3 lower_left_corner;
-    Vector3 horizontal;
-    Vector3 vertical;
-    Vector3 u;
-    Vector3 v;
-    Vector3 w;
-    float lens_radius;
+    static void store(float (&dst)[3], const Vector3& v) {
+        dst[0] = v.x();
+        dst[1] = v.y();
+        dst[2] = v.z();
+    }
+    static Vector3 load(const float (&src)[3]) { return Vector3{src[0], src[1], src[2]}; }
+
+    rtk_camera frame_{};
 };
