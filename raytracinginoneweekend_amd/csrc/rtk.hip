@@ -43,6 +43,9 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
         it.exact = sc.exact;
     }
     it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
+#if RTK_STAGED_LARGE
+    if (!LDS) it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
+#endif
     it.n = sc.n;
     it.fb = sc.fb;
     it.lane = lane;
@@ -50,7 +53,9 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     return it;
 }
 
-static size_t lds_bytes(bool lds, int npad) { return (lds ? static_cast<size_t>(npad) * 32 : 0) + kWavesPerBlock * kListCap * kWave * 2; }
+static size_t lds_bytes(bool lds, int npad) {
+    return (lds ? static_cast<size_t>(npad) * 32 : (RTK_STAGED_LARGE ? kWavesPerBlock * kStageSpheres * sizeof(float4) : 0)) + kWavesPerBlock * kListCap * kWave * 2;
+}
 
 template <bool LDS>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {

@@ -191,12 +191,30 @@ typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
 #define RTK_FILT_LOAD(i) (filt[i])
 #endif
 
+// RTK_STAGED_LARGE=1 (experiment build, default off until it has run on a GPU): scenes beyond kMaxLdsSpheres stream
+// the sphere list through a wave-private LDS chunk instead of reading every sphere with a broadcast global load.
+#ifndef RTK_STAGED_LARGE
+#define RTK_STAGED_LARGE 0
+#endif
+constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 32)
+#ifdef RTK_HOST_EMULATION
+#define RTK_WAVE_SYNC() ((void)__ballot(true))      // the fibers of a wave are not in lockstep between votes
+#else
+#define RTK_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
+
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
     const float4* filt_global;   // always the global-memory copy (RTK_SMEM reads through it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
+    float4* stage = nullptr;     // RTK_STAGED_LARGE: this wave's LDS chunk of kStageSpheres filter operands
     FilterBounds fb;
     int n;
     int lane;
@@ -320,30 +338,75 @@ struct Intersector {
             return active ? cand : 0u;
         };
 
-        const int full = n >> 5, rem = n & 31;
-        for (int w = 0; w < full; ++w) {
-            if (w * 32 - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
-                flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
-                list_base = w * 32;
-            }
-            uint32_t m = 0;
+        // filter + compaction over `count` consecutive spheres starting at list index `base`; load(i) yields the
+        // operands of sphere base + i
+        auto scan = [&](auto&& load, int base, int count) {
+            const int full = count >> 5, rem = count & 31;
+            for (int w = 0; w < full; ++w) {
+                if (base + w * 32 - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
+                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                    list_base = base + w * 32;
+                }
+                uint32_t m = 0;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const auto s = RTK_FILT_LOAD(w * 32 + i);
-                filter_one(f, s.x, s.y, s.z, s.w, m);
+                for (int i = 0; i < 32; ++i) {
+                    const auto s = load(w * 32 + i);
+                    filter_one(f, s.x, s.y, s.z, s.w, m);
+                }
+                RTK_STAT(lane, filter_words);
+                emit(base + w * 32, to_cand(m, 0xFFFFFFFFu));
             }
-            RTK_STAT(lane, filter_words);
-            emit(w * 32, to_cand(m, 0xFFFFFFFFu));
-        }
-        if (rem) {
-            uint32_t m = 0;
+            if (rem) {
+                uint32_t m = 0;
 #pragma unroll 4
-            for (int i = 0; i < rem; ++i) {
-                const auto s = RTK_FILT_LOAD(full * 32 + i);
-                filter_one(f, s.x, s.y, s.z, s.w, m);
+                for (int i = 0; i < rem; ++i) {
+                    const auto s = load(full * 32 + i);
+                    filter_one(f, s.x, s.y, s.z, s.w, m);
+                }
+                m <<= (32 - rem);
+                emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
-            m <<= (32 - rem);
-            emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+        };
+#if RTK_STAGED_LARGE
+        if (!LDS) {
+            // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced
+            // global load per 64 spheres instead of one broadcast load per sphere — and filters from LDS as usual.
+            // Only this wave touches `stage`; DS operations of a wave execute in order, so the chunk's writes are
+            // visible to its reads and the next chunk's writes cannot overtake this chunk's reads.
+            // The next chunk is fetched into registers before the current one is scanned, so its
+            // latency hides behind ~1150 filter instructions.
+            constexpr int kPerLane = kStageSpheres / kWave;
+#ifdef RTK_HOST_EMULATION
+            typedef float4 Quad;
+#else
+            typedef float Quad __attribute__((ext_vector_type(4)));     // a register quad the compiler keeps out of scratch
+#endif
+            const Quad* src = reinterpret_cast<const Quad*>(filt);
+            Quad* dst = reinterpret_cast<Quad*>(stage);
+            Quad pre[kPerLane];
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                const int i = j * kWave + lane;
+                pre[j] = src[i < n ? i : n - 1];
+            }
+            for (int base = 0; base < n; base += kStageSpheres) {
+                const int count = n - base < kStageSpheres ? n - base : kStageSpheres;
+                RTK_WAVE_SYNC();
+#pragma unroll
+                for (int j = 0; j < kPerLane; ++j)
+                    if (j * kWave + lane < count) dst[j * kWave + lane] = pre[j];
+                RTK_WAVE_SYNC();
+#pragma unroll
+                for (int j = 0; j < kPerLane; ++j) {          // unconditional (clamped) loads: no branch, so no wait before the scan
+                    const int i = base + kStageSpheres + j * kWave + lane;
+                    pre[j] = src[i < n ? i : n - 1];
+                }
+                scan([&](int i) { return stage[i]; }, base, count);
+            }
+        } else
+#endif
+        {
+            scan([&](int i) { return RTK_FILT_LOAD(i); }, 0, n);
         }
         flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         t_out = closest;

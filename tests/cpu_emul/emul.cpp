@@ -50,7 +50,7 @@ struct Emul {
     SceneDev dev;
 };
 
-static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0) {
+static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
     Intersector<false> it;
     it.filt = e.ps.filt.data();
     it.filt_global = e.ps.filt.data();
@@ -59,6 +59,7 @@ static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg
     it.fb = e.ps.fb;
     it.n = e.ps.n;
     it.lane = lane;
+    it.stage = stage;
     it.dbg_flags = dbg;
     return it;
 }
@@ -88,13 +89,15 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
     const Emul& e = *static_cast<Emul*>(h);
     rtk_shim::ulp_noise = ulp_noise;
     std::vector<uint16_t> list(kListCap * kWave);
+    std::vector<float4> stage(kStageSpheres);
     std::vector<uint32_t> ne_lane(kWave, 0);
     uint64_t total = 0;
     for (uint64_t base = 0; base < n; base += kWave) {
         run_lanes([&](int lane) {
             const uint64_t i = base + static_cast<uint64_t>(lane);
             const bool active = i < n;
-            const Intersector<false> it = make_isect(e, list.data(), (flags && active) ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr, lane);
+            const Intersector<false> it = make_isect(e, list.data(), (flags && active) ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr, lane,
+                                                     RTK_STAGED_LARGE ? stage.data() : nullptr);
             Ray r = {};
             if (active) {
                 const float* q = rays + 6 * i;
@@ -192,8 +195,9 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     for (int k = 0; k < threads; ++k)
         pool.emplace_back([&] {
             std::vector<uint16_t> list(kListCap * kWave);
+            std::vector<float4> stage(kStageSpheres);
             run_lanes([&](int lane) {
-                const Intersector<false> it = make_isect(e, list.data(), nullptr, lane);
+                const Intersector<false> it = make_isect(e, list.data(), nullptr, lane, RTK_STAGED_LARGE ? stage.data() : nullptr);
                 render_wave<false>(A, it);
             });
             fold_stats();

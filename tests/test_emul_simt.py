@@ -61,3 +61,45 @@ def test_wave_statistics_are_sane(e64):
     assert s["closest_hit_calls"] == st["passes"] and s["filter_words"] == 15 * st["passes"]
     assert st["rays"] / (64.0 * st["passes"]) > 0.9                      # per-lane refill keeps the lanes busy
     assert 1.0 < s["flush_iters"] / st["passes"] < 12.0
+
+
+# ---- RTK_STAGED_LARGE: libemul64.so is built with the staged large-scene path, so every 64-lane intersect above
+# already went through it (the emulation has no LDS-resident scene); these cases add the chunk boundaries. ----
+@pytest.mark.parametrize("n", [1, 63, 127, 128, 129, 160, 255, 256, 257, 1025])
+def test_staged_chunks_and_tails(n):
+    """Scenes around the 128-sphere chunk size: last chunk of 1, of a partial word, of exactly one chunk."""
+    from test_emul_intersect import _odd_scene, tangent_rays
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(100 + n)
+    s = _odd_scene(rng, n)
+    m = 1500
+    rays = np.concatenate([np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32),
+                           tangent_rays(rng, s, 700, 0.5, 200, 1e-5)])
+    o = po.Oracle(); o.set_scene(s)
+    ho, io, to = o.intersect(rays, 0.001, np.inf)
+    hit, idx, t = Emul(s, lanes=64).intersect(rays)
+    nan = np.isnan(to)
+    assert np.array_equal(hit, ho) and np.array_equal(idx, io)
+    assert np.array_equal(np.isnan(t), nan) and np.array_equal(bits(t)[~nan], bits(to)[~nan])
+    assert emul.lib(64).emul_simt_error() == 0
+
+
+@pytest.mark.parametrize("k,m", [(50, 640), (135, 192)])
+def test_staged_large_scenes(k, m):
+    """BASELINE.json config 4 (10k and ~73k spheres) through the staged path in 64-lane waves, unsafe rays included
+    (all spheres candidates: list flushes and the 64k re-base happen between staged chunks)."""
+    from oracle import pyoracle as po
+    s = rt.scaled_scene(k=k)
+    rng = np.random.default_rng(k)
+    ext = float(k)
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-ext, ext, m); rays[:, 1] = rng.uniform(0.01, 3, m); rays[:, 2] = rng.uniform(-ext, ext, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.15
+    rays[5:9, 3:6] = (np.nan, 1, 0)
+    o = po.Oracle(); o.set_scene(s)
+    ho, io, to = o.intersect(rays, 0.001, np.inf)
+    hit, idx, t = Emul(s, lanes=64).intersect(rays)
+    nan = np.isnan(to)
+    assert np.array_equal(hit, ho) and np.array_equal(idx, io)
+    assert np.array_equal(np.isnan(t), nan) and np.array_equal(bits(t)[~nan], bits(to)[~nan])
+    assert emul.lib(64).emul_simt_error() == 0
