@@ -22,6 +22,13 @@ using namespace rtk;
 // =================================================================================================
 
 // Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists.
+// RTK_EXACT_GLOBAL=1 (experiment build): the exact stage's operands stay in global memory (an 8 KiB table, L1-resident;
+// the loads are per-lane gathers either way), which takes the workgroup from 24 to 16 KiB of LDS: 7 waves per SIMD
+// (register-limited) instead of 6.
+#ifndef RTK_EXACT_GLOBAL
+#define RTK_EXACT_GLOBAL 0
+#endif
+constexpr int kLdsBytesPerSphere = RTK_EXACT_GLOBAL ? 16 : 32;
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
@@ -30,14 +37,19 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     unsigned char* p = smem;
     if (LDS) {
         float4* lf = reinterpret_cast<float4*>(p);
+#if RTK_EXACT_GLOBAL
+        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) lf[i] = sc.filt[i];
+        it.exact = sc.exact;
+#else
         float4* le = lf + sc.npad;
         for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) {
             lf[i] = sc.filt[i];
             le[i] = sc.exact[i];
         }
-        it.filt = lf;
         it.exact = le;
-        p += static_cast<size_t>(sc.npad) * 32;
+#endif
+        it.filt = lf;
+        p += static_cast<size_t>(sc.npad) * kLdsBytesPerSphere;
     } else {
         it.filt = sc.filt;
         it.exact = sc.exact;
@@ -54,7 +66,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 }
 
 static size_t lds_bytes(bool lds, int npad) {
-    return (lds ? static_cast<size_t>(npad) * 32 : (RTK_STAGED_LARGE ? kWavesPerBlock * kStageSpheres * sizeof(float4) : 0)) + kWavesPerBlock * kListCap * kWave * 2;
+    return (lds ? static_cast<size_t>(npad) * kLdsBytesPerSphere : (RTK_STAGED_LARGE ? kWavesPerBlock * kStageSpheres * sizeof(float4) : 0)) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 template <bool LDS>

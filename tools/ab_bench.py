@@ -12,8 +12,10 @@ for r in range(rounds):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--spp", spp, "--no-cpu-baseline"],
                              env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        if not line:
-            print(os.path.basename(lib), "FAILED", out.stderr[-400:]); continue
+        if out.returncode != 0 or not line:
+            # a variant that crashed may have faulted the GPU: start nothing more on it in this call
+            print(os.path.basename(lib), "FAILED (exit %d); stopping here" % out.returncode, out.stderr[-600:])
+            sys.exit(1)
         j = json.loads(line[-1])
         res.setdefault(os.path.basename(lib), []).append((j["value"], j["roofline"]["frac"], j["roofline"]["exact_tests_per_ray"], j["roofline"]["lane_utilisation"]))
 for k, v in res.items():

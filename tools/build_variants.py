@@ -14,6 +14,7 @@ VARIANTS = {
     "ship": [],                                    # projection filter, LDS broadcast operands
     "form0": ["-DRTK_FILTER_FORM=0"],              # discriminant filter (11 VALU / test)
     "smem": ["-DRTK_SMEM=1"],                      # filter operands by scalar loads from the GLOBAL copy (SGPR operands)
+    "exactg": ["-DRTK_EXACT_GLOBAL=1"],            # exact-stage operands from global memory: 16 instead of 24 KiB LDS per workgroup (7 waves/SIMD)
     "staged": ["-DRTK_STAGED_LARGE=1"],            # scenes > 1024 spheres: stream the list through wave-private LDS chunks (only differs for such scenes)
 }
 os.makedirs(OUT, exist_ok=True)
