@@ -164,4 +164,38 @@ inline RenderResult render_image(const Hittable& world, const Camera& camera, in
     return render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, 1, [](int, int) {}, seed, device);
 }
 
+// The reference's whole output step (main.cpp:57-76) in one call: render, apply write_color_binary ON THE DEVICE
+// (rtk_render_u8: a quarter of the bytes cross PCIe) and write header + payload of the P6 file.  The bytes equal
+// write_ppm_binary(render_image(...)) for the same seed.  Returns the frame's counters.
+inline rtk_stats render_ppm(std::ostream& out, const Hittable& world, const Camera& camera, int image_width, int image_height,
+                            int samples_per_pixel, int max_depth, uint64_t seed = 0, int device = 0) {
+    const FlatScene flat = flatten(world);
+    rtk_context* ctx = nullptr;
+    const auto check = [&ctx](int status, const char* what) {
+        if (status == RTK_OK) return;
+        const std::string msg = std::string(what) + ": " + rtk_last_error();
+        if (ctx) rtk_context_destroy(ctx);
+        throw std::runtime_error(msg);
+    };
+    check(rtk_context_create(device, &ctx), "rtk_context_create");
+    const rtk_scene view = flat.view();
+    check(rtk_set_scene(ctx, &view), "rtk_set_scene");
+    const rtk_camera cam = camera.export_fields();
+    rtk_params p{};
+    p.width = image_width;
+    p.height = image_height;
+    p.spp = samples_per_pixel;
+    p.max_depth = max_depth;
+    p.seed = seed;
+    p.t_min = 0.001f;
+    p.world_size = 1;
+    std::vector<uint8_t> bytes(static_cast<size_t>(image_width) * image_height * 3);
+    rtk_stats st{};
+    check(rtk_render_u8(ctx, &cam, &p, bytes.data(), &st), "rtk_render_u8");
+    rtk_context_destroy(ctx);
+    out << "P6\n" << image_width << ' ' << image_height << '\n' << 255 << '\n';
+    out.write(reinterpret_cast<const char*>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
+    return st;
+}
+
 } // namespace rtiow

@@ -153,6 +153,12 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
 int rtk_deinterleave_device(rtk_context* ctx, const float* d_gathered, int64_t tiles_per_rank_padded,
                             const rtk_params* p, float* d_image);
 
+/* The same for quantised bytes (rank-local tiles passed through rtk_quantise_device before the gather: a
+ * quarter of the bytes on xGMI): `d_gathered` is [world_size][tiles_per_rank_padded][64][3] bytes, `d_image`
+ * [height][width][3] bytes = the pixel payload of the reference's image_binary.ppm (main.cpp:57-76).  SURVEY.md §8f-1. */
+int rtk_deinterleave_u8_device(rtk_context* ctx, const uint8_t* d_gathered, int64_t tiles_per_rank_padded,
+                               const rtk_params* p, uint8_t* d_image);
+
 /* Whole image on one device into HOST memory: out_rgb_sum is [height][width][3] fp32 colour sums,
  * row 0 = top row.  Equivalent to the reference's loops main.cpp:64-76 with write_color_binary's
  * input captured instead of written.  p->rank/world_size must be 0/1 (or 0/0). */
@@ -161,6 +167,11 @@ int rtk_render(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, flo
 /* write_color_binary (Color.hpp:28-48) for n_pixels RGB sums: sqrt(sum/spp), clamp [0,1],
  * (uint8_t)(255*x).  DEVICE pointers, asynchronous.  Byte-exact with the reference for equal sums. */
 int rtk_quantise_device(rtk_context* ctx, const float* d_rgb_sum, int64_t n_pixels, int32_t spp, uint8_t* d_rgb_u8);
+
+/* rtk_render followed by write_color_binary on the device: out_rgb_u8 is [height][width][3] bytes in HOST memory,
+ * exactly the bytes main.cpp:64-76 streams after the PPM header (Color.hpp:28-48), a quarter of rtk_render's
+ * device-to-host copy.  p->sample_offset must be 0 (a complete frame of p->spp samples). */
+int rtk_render_u8(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, uint8_t* out_rgb_u8, rtk_stats* stats);
 
 /* HittableList::hit (HittableList.hpp:30-42) with Sphere3::hit (Sphere3.hpp:31-59) for a batch of
  * rays against the context's scene: HOST arrays; rays are 6 floats (origin, direction; direction

@@ -24,7 +24,7 @@ C_ABI_SYMBOLS = (
     "rtk_set_scene", "rtk_local_tile_count", "rtk_render_tiles_device", "rtk_deinterleave_device", "rtk_render",
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
-    "rtk_run_schedule",
+    "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8",
 )
 
 
@@ -87,7 +87,9 @@ def lib() -> C.CDLL:
         l.rtk_local_tile_count.restype = i64
         l.rtk_render_tiles_device.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
         l.rtk_deinterleave_device.argtypes = [vp, vp, i64, C.POINTER(rtk_params), vp]
+        l.rtk_deinterleave_u8_device.argtypes = [vp, vp, i64, C.POINTER(rtk_params), vp]
         l.rtk_render.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
+        l.rtk_render_u8.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
         l.rtk_quantise_device.argtypes = [vp, vp, i64, i32, vp]
         l.rtk_intersect_batch.argtypes = [vp, vp, sz, f32, f32, vp, vp, vp]
         l.rtk_intersect_batch_device.argtypes = [vp, vp, sz, f32, f32, vp, vp, vp]
@@ -243,6 +245,15 @@ class Context:
         _check(self._l.rtk_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(st)), "rtk_render")
         return out, st.as_dict()
 
+    def render_u8(self, cam22, W, H, spp, depth, seed=0, t_min=0.001, tile_w=8, tile_h=8, run_len=0):
+        """Whole image, quantised on the device -> (uint8 [H, W, 3] = the PPM payload, stats dict)."""
+        out = np.zeros((H, W, 3), np.uint8)
+        st = rtk_stats()
+        p = make_params(W, H, spp, depth, seed, t_min, 0, 1, tile_w, tile_h, run_len, 0)
+        cam = _cam_struct(cam22)
+        _check(self._l.rtk_render_u8(self._h, C.byref(cam), C.byref(p), out.ctypes.data, C.byref(st)), "rtk_render_u8")
+        return out, st.as_dict()
+
     def render_tiles_device(self, cam22, params: rtk_params, d_tile_sums_ptr: int, want_stats: bool = False):
         st = rtk_stats()
         cam = _cam_struct(cam22)
@@ -253,6 +264,10 @@ class Context:
     def deinterleave_device(self, d_gathered_ptr: int, tiles_per_rank_padded: int, params: rtk_params, d_image_ptr: int):
         _check(self._l.rtk_deinterleave_device(self._h, C.c_void_p(d_gathered_ptr), tiles_per_rank_padded, C.byref(params),
                                                C.c_void_p(d_image_ptr)), "rtk_deinterleave_device")
+
+    def deinterleave_u8_device(self, d_gathered_ptr: int, tiles_per_rank_padded: int, params: rtk_params, d_image_ptr: int):
+        _check(self._l.rtk_deinterleave_u8_device(self._h, C.c_void_p(d_gathered_ptr), tiles_per_rank_padded, C.byref(params),
+                                                  C.c_void_p(d_image_ptr)), "rtk_deinterleave_u8_device")
 
     def quantise_device(self, d_sum_ptr: int, n_pixels: int, spp: int, d_u8_ptr: int):
         _check(self._l.rtk_quantise_device(self._h, C.c_void_p(d_sum_ptr), n_pixels, spp, C.c_void_p(d_u8_ptr)),

@@ -85,8 +85,9 @@ __global__ void finalize_kernel(unsigned long long* accum, float* out, size_t n)
     }
 }
 
-// [world][tiles_per_rank_padded][64][3] -> [H][W][3]
-__global__ void deinterleave_kernel(const float* g, long long tprp, int W, int H, int tile_w, int tile_h, int tiles_x, int world, float* img) {
+// [world][tiles_per_rank_padded][64][3] -> [H][W][3]; T = float (colour sums) or uint8_t (quantised bytes)
+template <typename T>
+__global__ void deinterleave_kernel(const T* g, long long tprp, int W, int H, int tile_w, int tile_h, int tiles_x, int world, T* img) {
     const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
     if (p >= static_cast<long long>(W) * H) return;
     const int x = static_cast<int>(p % W), row = static_cast<int>(p / W);
@@ -230,6 +231,7 @@ struct rtk_context {
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // batch entry points
     DevBuf tile_out;     // for rtk_render (host output)
     DevBuf image_out;
+    DevBuf image_u8;     // for rtk_render_u8
 };
 
 static bool use_lds(const rtk_context* c) { return c->scene.n <= kMaxLdsSpheres; }
@@ -285,7 +287,7 @@ void rtk_context_destroy(rtk_context* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
-                      &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out})
+                      &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
@@ -496,8 +498,9 @@ int rtk_get_stats(rtk_context* c, rtk_stats* stats) {
     return RTK_OK;
 }
 
-int rtk_deinterleave_device(rtk_context* c, const float* d_gathered, int64_t tprp, const rtk_params* p, float* d_image) {
-    if (!c || !d_gathered || !p || !d_image) return fail(RTK_ERR_BAD_ARG, "rtk_deinterleave_device: null argument");
+extern "C++" template <typename T>
+static int deinterleave_any(rtk_context* c, const T* d_gathered, int64_t tprp, const rtk_params* p, T* d_image, const char* who) {
+    if (!c || !d_gathered || !p || !d_image) return fail(RTK_ERR_BAD_ARG, "%s: null argument", who);
     int tw, th;
     if (int e = norm_tiles(p, tw, th)) return e;
     const int world = p->world_size > 0 ? p->world_size : 1;
@@ -505,10 +508,18 @@ int rtk_deinterleave_device(rtk_context* c, const float* d_gathered, int64_t tpr
     if (tprp < rtk_local_tile_count(p->width, p->height, tw, th, 0, world)) return fail(RTK_ERR_BAD_ARG, "tiles_per_rank_padded %lld is too small", static_cast<long long>(tprp));
     HIP_TRY(hipSetDevice(c->device));
     const long long np = static_cast<long long>(p->width) * p->height;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, c->stream, d_gathered, static_cast<long long>(tprp),
+    hipLaunchKernelGGL(deinterleave_kernel<T>, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, c->stream, d_gathered, static_cast<long long>(tprp),
                        p->width, p->height, tw, th, (p->width + tw - 1) / tw, world, d_image);
     HIP_TRY(hipGetLastError());
     return RTK_OK;
+}
+
+int rtk_deinterleave_device(rtk_context* c, const float* d_gathered, int64_t tprp, const rtk_params* p, float* d_image) {
+    return deinterleave_any<float>(c, d_gathered, tprp, p, d_image, "rtk_deinterleave_device");
+}
+
+int rtk_deinterleave_u8_device(rtk_context* c, const uint8_t* d_gathered, int64_t tprp, const rtk_params* p, uint8_t* d_image) {
+    return deinterleave_any<uint8_t>(c, d_gathered, tprp, p, d_image, "rtk_deinterleave_u8_device");
 }
 
 int rtk_render(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* out, rtk_stats* stats) {
@@ -529,6 +540,34 @@ int rtk_render(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float
     if (int e = rtk_render_tiles_device(c, cam, &q, static_cast<float*>(c->tile_out.p), &st)) return e;
     if (int e = rtk_deinterleave_device(c, static_cast<const float*>(c->tile_out.p), nlt, &q, static_cast<float*>(c->image_out.p))) return e;
     HIP_TRY(hipMemcpyAsync(out, c->image_out.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) *stats = st;
+    return RTK_OK;
+}
+
+int rtk_quantise_device(rtk_context* c, const float* d_sum, int64_t n_pixels, int32_t spp, uint8_t* d_u8);
+
+int rtk_render_u8(rtk_context* c, const rtk_camera* cam, const rtk_params* p, uint8_t* out, rtk_stats* stats) {
+    if (!c || !cam || !p || !out) return fail(RTK_ERR_BAD_ARG, "rtk_render_u8: null argument");
+    if (p->world_size > 1 || p->rank != 0) return fail(RTK_ERR_BAD_ARG, "rtk_render_u8 renders the whole image: rank/world_size must be 0/1");
+    if (p->sample_offset != 0) return fail(RTK_ERR_BAD_ARG, "rtk_render_u8 quantises a complete frame: sample_offset must be 0 (sum progressive batches with rtk_render)");
+    int tw, th;
+    if (int e = norm_tiles(p, tw, th)) return e;
+    if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
+    HIP_TRY(hipSetDevice(c->device));
+    rtk_params q = *p;
+    q.world_size = 1;
+    q.rank = 0;
+    const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, 0, 1);
+    const size_t np = static_cast<size_t>(p->width) * p->height;
+    HIP_TRY(c->tile_out.reserve(static_cast<size_t>(nlt) * kTilePixels * 3 * sizeof(float)));
+    HIP_TRY(c->image_out.reserve(np * 3 * sizeof(float)));
+    HIP_TRY(c->image_u8.reserve(np * 3));
+    rtk_stats st;
+    if (int e = rtk_render_tiles_device(c, cam, &q, static_cast<float*>(c->tile_out.p), &st)) return e;
+    if (int e = rtk_deinterleave_device(c, static_cast<const float*>(c->tile_out.p), nlt, &q, static_cast<float*>(c->image_out.p))) return e;
+    if (int e = rtk_quantise_device(c, static_cast<const float*>(c->image_out.p), static_cast<int64_t>(np), p->spp, static_cast<uint8_t*>(c->image_u8.p))) return e;
+    HIP_TRY(hipMemcpyAsync(out, c->image_u8.p, np * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (stats) *stats = st;
     return RTK_OK;

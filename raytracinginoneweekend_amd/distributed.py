@@ -48,6 +48,8 @@ class ShardedRenderer:
         self.tprp = tiles_per_rank_padded(W, H, world, tile_w, tile_h)
         self.local = torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.float32, device=device)
         self.image = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+        self.local_u8 = None     # allocated on the first render(..., output="u8")
+        self.image_u8 = None
         self.stream = torch.cuda.Stream(device=device)
         self.stream.wait_stream(torch.cuda.current_stream(device))     # the zero-fills above
         assert self.stream.cuda_stream != 0
@@ -57,16 +59,28 @@ class ShardedRenderer:
     def params(self, spp: int, depth: int, seed: int = 0, run_len: int = 0):
         return make_params(self.W, self.H, spp, depth, seed, 0.001, self.rank, self.world, self.tile_w, self.tile_h, run_len)
 
-    def render(self, cam22, spp: int, depth: int, seed: int = 0, want_stats: bool = False, assemble: bool = True):
+    def render(self, cam22, spp: int, depth: int, seed: int = 0, want_stats: bool = False, assemble: bool = True, output: str = "f32"):
         """Render this rank's tiles, gather, de-interleave (asynchronous on self.stream).  Returns stats (or None);
-        the image is self.image once self.stream has been synchronised."""
+        the image is self.image (output="f32": colour sums) or self.image_u8 (output="u8": every rank applies
+        write_color_binary to its own tiles first, so the gather moves a quarter of the bytes)
+        once self.stream has been synchronised."""
+        if output not in ("f32", "u8"):
+            raise ValueError("output must be 'f32' or 'u8'")
         p = self.params(spp, depth, seed)
         with torch.cuda.stream(self.stream):
+            if output == "u8" and self.local_u8 is None:
+                self.local_u8 = torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.uint8, device=self.device)
+                self.image_u8 = torch.zeros((self.H, self.W, 3), dtype=torch.uint8, device=self.device)
             st = self.ctx.render_tiles_device(cam22, p, self.local.data_ptr(), want_stats)
-            if assemble:
+            if assemble and output == "f32":
                 gathered = gather_tiles(self.local)
                 self.ctx.deinterleave_device(gathered.data_ptr(), self.tprp, p, self.image.data_ptr())
                 self._keep = gathered   # keep the buffer alive until the next frame has been queued behind this one
+            elif assemble:
+                self.ctx.quantise_device(self.local.data_ptr(), self.tprp * TILE_PIXELS, spp, self.local_u8.data_ptr())
+                gathered = gather_tiles(self.local_u8)
+                self.ctx.deinterleave_u8_device(gathered.data_ptr(), self.tprp, p, self.image_u8.data_ptr())
+                self._keep = gathered
         return st
 
     def synchronize(self) -> None:

@@ -42,18 +42,24 @@ int main(int argc, char** argv) {
 
     std::ofstream bin_file("image_binary.ppm", std::ios_base::binary);
     try {
-        rtiow::RenderResult frame;
+        rtk_stats stats{};
         {
             PROFILE_LOG_SCOPE("Image Generation");
             std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
-            frame = rtiow::render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, batches,
-                                                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; },
-                                                    seed, device);
-            rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
+            if (batches <= 1) {
+                // one pass: gamma and quantisation run on the device, the file is one write
+                stats = rtiow::render_ppm(bin_file, world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device);
+            } else {
+                const rtiow::RenderResult frame = rtiow::render_image_progressive(
+                    world, camera, image_width, image_height, samples_per_pixel, max_depth, batches,
+                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; }, seed, device);
+                rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
+                stats = frame.stats;
+            }
             std::cerr << "\rScanlines remaining: 0 \nDone.\n";
         }
-        std::cerr << "rays " << frame.stats.rays << "  kernel " << frame.stats.kernel_ms << " ms  "
-                  << (frame.stats.kernel_ms > 0 ? frame.stats.rays / (frame.stats.kernel_ms * 1e3) : 0.0) << " Mrays/s\n";
+        std::cerr << "rays " << stats.rays << "  kernel " << stats.kernel_ms << " ms  "
+                  << (stats.kernel_ms > 0 ? stats.rays / (stats.kernel_ms * 1e3) : 0.0) << " Mrays/s\n";
     } catch (const std::exception& e) {
         std::cerr << "\nerror: " << e.what() << '\n';
         return 1;

@@ -13,7 +13,7 @@ import raytracinginoneweekend_amd as rt
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "rtk.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rtk_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rtk_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_python_agree():

@@ -40,6 +40,10 @@ def _worker(rank, world, W, H, port, out_dir):
     assert tuple(gathered.shape) == (world, tprp, 64, 3)
     img = deinterleave(gathered.numpy(), W, H, world)
     np.save(os.path.join(out_dir, f"img{rank}.npy"), img)
+    # the quantised path: the same gather on uint8 tiles
+    g8 = rd.gather_tiles((local % 251).to(torch.uint8))
+    assert g8.dtype == torch.uint8 and tuple(g8.shape) == (world, tprp, 64, 3)
+    np.save(os.path.join(out_dir, f"img8_{rank}.npy"), deinterleave(g8.numpy(), W, H, world))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,3 +60,5 @@ def test_shard_gather_deinterleave(tmp_path, world, W, H):
         img = np.load(tmp_path / f"img{r}.npy")
         assert np.array_equal(img[..., 0], p) and np.array_equal(img[..., 1], 2 * p + 1)
         assert np.array_equal(img[..., 2], owner)          # every pixel came from the rank that owns its tile
+        img8 = np.load(tmp_path / f"img8_{r}.npy")
+        assert img8.dtype == np.uint8 and np.array_equal(img8[..., 0], (p % 251).astype(np.uint8))

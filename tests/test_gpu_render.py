@@ -248,3 +248,43 @@ def test_sharded_renderer_single_rank_matches_rtk_render(stock_scene_golden):
         assert np.array_equal(bits(sr.image.cpu().numpy()), bits(ref))
     ctx.set_stream(0)
     ctx.close()
+
+
+def test_render_u8_is_write_color_binary_of_render(gpu_ctx):
+    """rtk_render_u8: the device-side gamma/quantise gives exactly the bytes the reference's
+    write_color_binary (Color.hpp:28-48, restated by the oracle) produces from rtk_render's sums."""
+    cam = rt.stock_camera(1.5)
+    sums, st = gpu_ctx.render(cam, 90, 60, 20, 50, seed=12)
+    u8, st8 = gpu_ctx.render_u8(cam, 90, 60, 20, 50, seed=12)
+    assert st["rays"] == st8["rays"]
+    assert np.array_equal(u8, po.quantise(sums, 20))
+    with pytest.raises(rt.RtkError, match="null"):
+        rt._check(rt.lib().rtk_render_u8(gpu_ctx._h, None, None, None, None), "rtk_render_u8")
+
+
+def test_sharded_u8_gather_matches_f32_path(stock_scene_golden):
+    """ShardedRenderer(output="u8"): tiles quantised before the gather, bytes de-interleaved on the device."""
+    import torch
+    from raytracinginoneweekend_amd.distributed import ShardedRenderer
+    ctx = rt.Context(0)
+    ctx.set_scene(stock_scene_golden)
+    W, H, spp = 100, 60, 16
+    cam = rt.stock_camera(W / H)
+    sr = ShardedRenderer(ctx, W, H, 0, 1, torch.device("cuda", 0))
+    sr.render(cam, spp, 50, seed=4)
+    sr.synchronize()
+    want = po.quantise(sr.image.cpu().numpy(), spp)
+    sr.render(cam, spp, 50, seed=4, output="u8")
+    sr.synchronize()
+    assert np.array_equal(sr.image_u8.cpu().numpy(), want)
+    # the byte de-interleave for several ranks, against the numpy restatement of the index math
+    world = 3
+    tprp = rt.local_tile_count(W, H, 0, world)
+    g = torch.randint(0, 256, (world, tprp, 64, 3), dtype=torch.uint8, device="cuda:0")
+    img = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.deinterleave_u8_device(g.data_ptr(), tprp, rt.make_params(W, H, 1, 1, 0, 0.001, 0, world), img.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(img.cpu().numpy(), deinterleave(g.cpu().numpy(), W, H, world))
+    ctx.set_stream(0)
+    ctx.close()
