@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene-k", type=int, default=0,
+                    help="0: the stock 484-sphere scene (the metric's workload).  K > 0: BASELINE.json config 4, the same generator on a [-K,K)^2 grid (K=50: 10k spheres)")
+    ap.add_argument("--accel", choices=("list", "grid"), default="list",
+                    help="list: the reference's list walk (the metric's path, roofline applies).  grid: uniform grid (SURVEY.md §8f-3), same image, reported separately")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,8 +107,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     ctx = rt.Context(local_rank)
-    scene = rt.stock_scene()
+    scene = rt.stock_scene() if args.scene_k <= 0 else rt.scaled_scene(k=args.scene_k)
     ctx.set_scene(scene)
+    if args.accel == "grid" and ctx.set_accel(rt.ACCEL_GRID) != rt.ACCEL_GRID:
+        raise SystemExit("the grid was refused for this scene: " + rt.lib().rtk_last_error().decode())
     cam = rt.stock_camera(float(np.float32(args.width) / np.float32(args.height)))
     sr = ShardedRenderer(ctx, args.width, args.height, rank, world, device)
 
@@ -154,21 +160,31 @@ def main():
                 traffic = tj.get("bytes_per_launch") if tj.get("kernel_tag") == KERNEL_TAG else None
             except Exception:
                 traffic = None
+        headline = args.scene_k <= 0 and args.accel == "list"
         out = {
-            "metric": "Mrays/s (whole node), final scene 1200x800 500spp",
+            "metric": "Mrays/s (whole node), final scene 1200x800 500spp" if headline else
+                      "Mrays/s (whole node), NOT the headline workload: %s, %s" % ("stock scene" if args.scene_k <= 0 else "config-4 scene k=%d (%d spheres)" % (args.scene_k, n_spheres),
+                                                                                  "uniform grid" if args.accel == "grid" else "list walk"),
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: book-1 final random-spheres scene (484 spheres, libstdc++ default-seeded), "
-                                   f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}, stock camera",
+            "config": {"workload": ("BASELINE.json configs[1]: book-1 final random-spheres scene (484 spheres, libstdc++ default-seeded), " if args.scene_k <= 0 else
+                                    f"BASELINE.json configs[3] (scaled list): {n_spheres} spheres on [-{args.scene_k},{args.scene_k})^2, ") +
+                                   f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}, stock camera, closest hit by " +
+                                   ("uniform grid (bit-identical image, fewer sphere tests; not the roofline's algorithm)" if args.accel == "grid" else "list walk"),
                        "sharding": f"8x8-pixel tiles interleaved over {world} rank(s), one all_gather of fp32 tile sums per frame",
                        "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
-                         "traffic": traffic, "kernel": "render_kernel<true>", "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                         "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays,
                          "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.accel == "grid":
+            # the 17-flop-per-test model prices the list walk; with a grid the useful figure is tests per ray
+            out["roofline"] = {"bound": "valu_fp32", "achieved": None, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "kernel": "render_kernel<false, true>", "kernel_ms": k_ms, "exact_tests_per_ray": exact / max(1.0, rays),
+                               "note": "uniform grid: algorithmic work differs from the list walk; compare Mrays/s with --accel list on the same scene"}
+        if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     # tear down in order: the context must not outlive the torch stream it was pointed at

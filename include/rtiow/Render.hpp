@@ -109,7 +109,7 @@ struct RenderResult {
 template <class Progress>
 inline RenderResult render_image_progressive(const Hittable& world, const Camera& camera, int image_width, int image_height,
                                              int samples_per_pixel, int max_depth, int batches, Progress&& progress, uint64_t seed = 0,
-                                             int device = 0) {
+                                             int device = 0, int accel = RTK_ACCEL_LIST) {
     const FlatScene flat = flatten(world);
     rtk_context* ctx = nullptr;
     const auto check = [&ctx](int status, const char* what) {
@@ -119,6 +119,7 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
         throw std::runtime_error(msg);
     };
     check(rtk_context_create(device, &ctx), "rtk_context_create");
+    check(rtk_context_set_accel(ctx, accel), "rtk_context_set_accel");     // RTK_ACCEL_GRID: same image, far fewer sphere tests
     const rtk_scene view = flat.view();
     check(rtk_set_scene(ctx, &view), "rtk_set_scene");
     const rtk_camera cam = camera.export_fields();
@@ -160,15 +161,15 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
 }
 
 inline RenderResult render_image(const Hittable& world, const Camera& camera, int image_width, int image_height, int samples_per_pixel,
-                                 int max_depth, uint64_t seed = 0, int device = 0) {
-    return render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, 1, [](int, int) {}, seed, device);
+                                 int max_depth, uint64_t seed = 0, int device = 0, int accel = RTK_ACCEL_LIST) {
+    return render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, 1, [](int, int) {}, seed, device, accel);
 }
 
 // The reference's whole output step (main.cpp:57-76) in one call: render, apply write_color_binary ON THE DEVICE
 // (rtk_render_u8: a quarter of the bytes cross PCIe) and write header + payload of the P6 file.  The bytes equal
 // write_ppm_binary(render_image(...)) for the same seed.  Returns the frame's counters.
 inline rtk_stats render_ppm(std::ostream& out, const Hittable& world, const Camera& camera, int image_width, int image_height,
-                            int samples_per_pixel, int max_depth, uint64_t seed = 0, int device = 0) {
+                            int samples_per_pixel, int max_depth, uint64_t seed = 0, int device = 0, int accel = RTK_ACCEL_LIST) {
     const FlatScene flat = flatten(world);
     rtk_context* ctx = nullptr;
     const auto check = [&ctx](int status, const char* what) {
@@ -178,6 +179,7 @@ inline rtk_stats render_ppm(std::ostream& out, const Hittable& world, const Came
         throw std::runtime_error(msg);
     };
     check(rtk_context_create(device, &ctx), "rtk_context_create");
+    check(rtk_context_set_accel(ctx, accel), "rtk_context_set_accel");
     const rtk_scene view = flat.view();
     check(rtk_set_scene(ctx, &view), "rtk_set_scene");
     const rtk_camera cam = camera.export_fields();

@@ -118,6 +118,21 @@ void rtk_context_destroy(rtk_context* ctx);
  * NULL selects the context's own stream.  For callers that own device memory, e.g. torch. */
 int rtk_context_set_stream(rtk_context* ctx, void* hip_stream);
 
+/* How the closest hit is found.  No counterpart in the reference, whose HittableList::hit (HittableList.hpp:30-42)
+ * walks the whole list for every ray; SURVEY.md §8f-3.
+ *   RTK_ACCEL_LIST (default): the list walk — every ray meets every sphere; the path the roofline is quoted on.
+ *   RTK_ACCEL_GRID: a uniform grid over the spheres, built by the library at rtk_set_scene / at this call; a ray
+ *     tests only the spheres registered in the cells it crosses.  Results (hit, index, t, images, ray counts) are
+ *     bit-identical to the list walk; rays the grid's margins were not sized for (non-finite, origins farther than
+ *     the scene's diagonal from its centre) take the list walk inside the same kernel.  Meant for lists far beyond
+ *     the 1024 spheres that fit in LDS (BASELINE.json config 4).
+ * A scene that cannot be put in a grid (a non-finite sphere: the reference's result then depends on the LIST order)
+ * is rendered with the list walk; rtk_accel_in_use tells which one the next call will take and rtk_last_error()
+ * holds the reason after rtk_context_set_accel / rtk_set_scene. */
+enum { RTK_ACCEL_LIST = 0, RTK_ACCEL_GRID = 1 };
+int rtk_context_set_accel(rtk_context* ctx, int32_t mode);
+int rtk_accel_in_use(rtk_context* ctx);
+
 /* Upload the flattened world.  Replaces the traversal state HittableList::hit walks
  * (HittableList.hpp:27,34): precomputes, bit-identically to the reference's own fp32 operations,
  * radius*radius (Sphere3.hpp:35) and 1/radius (Vector3.cpp:35-37 via Sphere3.hpp:54). */

@@ -24,8 +24,9 @@ C_ABI_SYMBOLS = (
     "rtk_set_scene", "rtk_local_tile_count", "rtk_render_tiles_device", "rtk_deinterleave_device", "rtk_render",
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
-    "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8",
+    "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8", "rtk_context_set_accel", "rtk_accel_in_use",
 )
+ACCEL_LIST, ACCEL_GRID = 0, 1
 
 
 class RtkError(RuntimeError):
@@ -83,6 +84,8 @@ def lib() -> C.CDLL:
         l.rtk_context_destroy.restype = None
         l.rtk_context_set_stream.argtypes = [vp, vp]
         l.rtk_set_scene.argtypes = [vp, C.POINTER(rtk_scene)]
+        l.rtk_context_set_accel.argtypes = [vp, i32]
+        l.rtk_accel_in_use.argtypes = [vp]
         l.rtk_local_tile_count.argtypes = [i32, i32, i32, i32, i32, i32]
         l.rtk_local_tile_count.restype = i64
         l.rtk_render_tiles_device.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
@@ -224,6 +227,14 @@ class Context:
         s.mat_type = arrs["mat_type"].ctypes.data_as(C.POINTER(C.c_int32))
         _check(self._l.rtk_set_scene(self._h, C.byref(s)), "rtk_set_scene")
         self.n = s.n
+
+    def set_accel(self, mode: int) -> int:
+        """ACCEL_LIST (default) or ACCEL_GRID; returns the mode the next call will really use for the current scene."""
+        _check(self._l.rtk_context_set_accel(self._h, mode), "rtk_context_set_accel")
+        return self._l.rtk_accel_in_use(self._h)
+
+    def accel_in_use(self) -> int:
+        return self._l.rtk_accel_in_use(self._h)
 
     def reset_stats(self) -> None:
         _check(self._l.rtk_reset_stats(self._h), "rtk_reset_stats")

@@ -69,11 +69,12 @@ static size_t lds_bytes(bool lds, int npad) {
     return (lds ? static_cast<size_t>(npad) * kLdsBytesPerSphere : (RTK_STAGED_LARGE ? kWavesPerBlock * kStageSpheres * sizeof(float4) : 0)) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
-template <bool LDS>
+// GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
+template <bool LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);
-    render_wave<LDS>(A, isect);
+    render_wave<LDS, GRID>(A, isect);
 }
 
 // accumulators -> fp32 sums, and clear them for the next frame.
@@ -110,9 +111,9 @@ __global__ void quantise_kernel(const float* sums, long long n, int spp, uint8_t
     out[i] = static_cast<uint8_t>(static_cast<int>(255.0f * v));
 }
 
-template <bool LDS>
+template <bool LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlockThreads) void intersect_kernel(const SceneDev sc, const float* rays, size_t n, float t_min, float t_max,
-                                                                   uint8_t* out_hit, int32_t* out_index, float* out_t) {
+                                                                   uint8_t* out_hit, int32_t* out_index, float* out_t, const GridDev grid) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Intersector<LDS> isect = make_intersector<LDS>(sc, smem);
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(kBlockThreads) void intersect_kernel(const SceneDev
         float t;
         int idx;
         uint32_t n_exact = 0;
-        isect.closest_hit(r, active, t_min, t_max, t, idx, n_exact);
+        if (GRID) isect.closest_hit_grid(grid, r, active, t_min, t_max, t, idx, n_exact);
+        else isect.closest_hit(r, active, t_min, t_max, t, idx, n_exact);
         if (active) {
             out_hit[i] = idx >= 0 ? 1 : 0;
             out_index[i] = idx;
@@ -232,9 +234,52 @@ struct rtk_context {
     DevBuf tile_out;     // for rtk_render (host output)
     DevBuf image_out;
     DevBuf image_u8;     // for rtk_render_u8
+    // uniform grid (rtk_context_set_accel)
+    int accel = RTK_ACCEL_LIST;
+    bool grid_ok = false;            // a grid of the current scene is resident
+    GridDev grid = {};
+    DevBuf g_cells, g_items, g_always;
+    int blocks_per_cu_grid = 1;
+    std::vector<float> h_cx, h_cy, h_cz, h_radius;   // host copy of the geometry, for building the grid after rtk_set_scene
 };
 
 static bool use_lds(const rtk_context* c) { return c->scene.n <= kMaxLdsSpheres; }
+static bool use_grid(const rtk_context* c) { return c->accel == RTK_ACCEL_GRID && c->grid_ok; }
+
+static size_t lds_bytes(bool lds, int npad);
+
+// Builds the uniform grid of the resident scene and uploads it.  A scene a grid cannot hold (build_grid's reasons)
+// leaves grid_ok false with the reason in rtk_last_error(): rendering then walks the list as usual.
+static int upload_grid(rtk_context* c) {
+    c->grid_ok = false;
+    if (!c->have_scene) return RTK_OK;
+    rtk_scene geo = {};
+    geo.n = c->scene.n;
+    geo.cx = c->h_cx.data(); geo.cy = c->h_cy.data(); geo.cz = c->h_cz.data(); geo.radius = c->h_radius.data();
+    PreparedScene none;
+    GridHost g;
+    build_grid(&geo, none, g);
+    if (!g.usable) {
+        fail(RTK_OK, "uniform grid not used: %s", g.why);
+        return RTK_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->g_cells.reserve(g.cell_start.size() * sizeof(uint32_t)));
+    HIP_TRY(c->g_items.reserve(g.items.size() * sizeof(uint32_t)));
+    HIP_TRY(c->g_always.reserve(g.always.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(c->g_cells.p, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->g_items.p, g.items.data(), g.items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->g_always.p, g.always.data(), g.always.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->grid = g.dev;
+    c->grid.cell_start = static_cast<const uint32_t*>(c->g_cells.p);
+    c->grid.items = static_cast<const uint32_t*>(c->g_items.p);
+    c->grid.always = static_cast<const uint32_t*>(c->g_always.p);
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false, true>, kBlockThreads, lds_bytes(false, c->scene.npad)));
+    c->blocks_per_cu_grid = nb > 0 ? nb : 1;
+    c->grid_ok = true;
+    return RTK_OK;
+}
 
 extern "C" {
 
@@ -287,7 +332,7 @@ void rtk_context_destroy(rtk_context* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
-                      &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8})
+                      &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
@@ -334,6 +379,10 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
                 static_cast<const float4*>(c->mat1.p), n, npad, fb};
     c->have_scene = true;
+    c->h_cx.assign(s->cx, s->cx + n); c->h_cy.assign(s->cy, s->cy + n); c->h_cz.assign(s->cz, s->cz + n); c->h_radius.assign(s->radius, s->radius + n);
+    c->grid_ok = false;
+    if (c->accel == RTK_ACCEL_GRID)
+        if (int e = upload_grid(c)) return e;
     // persistent-grid sizing for both kernel flavours at this scene size
     for (int l = 0; l < 2; ++l) {
         int nb = 0;
@@ -350,6 +399,18 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     }
     return RTK_OK;
 }
+
+int rtk_context_set_accel(rtk_context* c, int32_t mode) {
+    if (!c) return fail(RTK_ERR_BAD_ARG, "null context");
+    if (mode != RTK_ACCEL_LIST && mode != RTK_ACCEL_GRID) return fail(RTK_ERR_BAD_ARG, "rtk_context_set_accel: unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(c->device));
+    c->accel = mode;
+    g_err[0] = 0;
+    if (mode == RTK_ACCEL_GRID && !c->grid_ok) return upload_grid(c);
+    return RTK_OK;
+}
+
+int rtk_accel_in_use(rtk_context* c) { return (c && use_grid(c)) ? RTK_ACCEL_GRID : RTK_ACCEL_LIST; }
 
 static int norm_tiles(const rtk_params* p, int& tw, int& th) {
     tw = p->tile_w;
@@ -440,15 +501,19 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     A.queue = static_cast<uint32_t*>(c->control.p);
     A.stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->control.p) + 256);
 
-    const bool lds = use_lds(c);
+    const bool accel = use_grid(c);
+    const bool lds = use_lds(c) && !accel;
     const size_t shm = lds_bytes(lds, c->scene.npad);
-    int64_t grid = static_cast<int64_t>(c->n_cu) * c->blocks_per_cu[lds ? 1 : 0];
+    A.grid = c->grid;
+    int64_t grid = static_cast<int64_t>(c->n_cu) * (accel ? c->blocks_per_cu_grid : c->blocks_per_cu[lds ? 1 : 0]);
     const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
     const int slot = c->n_frames % rtk_context::kEventPairs;
     HIP_TRY(hipEventRecord(c->kev[2 * slot], c->stream));
-    if (lds)
+    if (accel)
+        hipLaunchKernelGGL((render_kernel<false, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
+    else if (lds)
         hipLaunchKernelGGL(render_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
     else
         hipLaunchKernelGGL(render_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
@@ -482,7 +547,8 @@ int rtk_get_stats(rtk_context* c, rtk_stats* stats) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     stats->rays = h[0];
     stats->samples = h[1];
-    stats->sphere_tests = h[0] * static_cast<uint64_t>(c->scene.n);
+    // list walk: every ray meets every sphere; grid: only the exact tests of the cells it crosses
+    stats->sphere_tests = use_grid(c) ? h[2] : h[0] * static_cast<uint64_t>(c->scene.n);
     stats->exact_tests = h[2];
     stats->lane_slots = h[3] * kWave;
     stats->frames = static_cast<uint32_t>(c->n_frames);
@@ -588,15 +654,19 @@ int rtk_intersect_batch_device(rtk_context* c, const float* d_rays, size_t n, fl
     if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_intersect_batch: call rtk_set_scene first");
     if (n == 0) return RTK_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const bool lds = use_lds(c);
+    const bool accel = use_grid(c);
+    const bool lds = use_lds(c) && !accel;
     const size_t shm = lds_bytes(lds, c->scene.npad);
     size_t grid = (n + kBlockThreads - 1) / kBlockThreads;
-    const size_t cap = static_cast<size_t>(c->n_cu) * (c->blocks_per_cu[lds ? 1 : 0] > 0 ? c->blocks_per_cu[lds ? 1 : 0] : 1);
+    const int bpc = accel ? c->blocks_per_cu_grid : c->blocks_per_cu[lds ? 1 : 0];
+    const size_t cap = static_cast<size_t>(c->n_cu) * (bpc > 0 ? bpc : 1);
     if (grid > cap) grid = cap;
-    if (lds)
-        hipLaunchKernelGGL(intersect_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t);
+    if (accel)
+        hipLaunchKernelGGL((intersect_kernel<false, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
+    else if (lds)
+        hipLaunchKernelGGL(intersect_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
     else
-        hipLaunchKernelGGL(intersect_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t);
+        hipLaunchKernelGGL(intersect_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
     HIP_TRY(hipGetLastError());
     return RTK_OK;
 }

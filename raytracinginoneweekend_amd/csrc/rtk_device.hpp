@@ -208,6 +208,25 @@ constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 
     } while (0)
 #endif
 
+// Uniform grid over the scene (no counterpart in the reference, whose HittableList::hit is O(N)).
+// Built on the host (rtk_scene_prep.hpp build_grid); opt-in (rtk_context_set_accel), for lists far beyond LDS size.
+// Every "gridable" sphere is registered in each cell its box overlaps, the box being inflated by everything the
+// reference's rounding could still accept for ray origins inside the ball (centre, r_allow); the few spheres that
+// are not gridable (non-finite, outliers such as the 1000-unit ground sphere) are tested for every ray.
+struct GridDev {
+    const uint32_t* cell_start;   // [nx*ny*nz + 1]
+    const uint32_t* items;        // sphere indices, ascending within a cell
+    const uint32_t* always;       // [n_always] ascending: spheres outside the grid
+    int32_t n_always;
+    int32_t nx, ny, nz;
+    float lox, loy, loz;          // grid box
+    float hix, hiy, hiz;
+    float hx, hy, hz;             // cell size
+    float ihx, ihy, ihz;          // 1 / cell size
+    float cx, cy, cz, r_allow2;   // ray origins inside this ball may use the grid; others take the brute-force path
+    float slack;                  // distance by which traversal decisions are widened (float error of the walk)
+};
+
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
@@ -409,6 +428,93 @@ struct Intersector {
             scan([&](int i) { return RTK_FILT_LOAD(i); }, 0, n);
         }
         flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+        t_out = closest;
+        idx_out = best;
+    }
+
+    // Closest hit through the uniform grid: same result as closest_hit(), bit for bit.
+    // For a finite ray and range the reference's answer does not depend on the order the spheres are visited in:
+    // a sphere's root is chosen against t_min alone whenever it could still win, so the list walk of
+    // HittableList.hpp:34-38 yields (min root, then max index).  Lanes whose ray or range is not finite, or whose
+    // origin lies outside the ball the grid's margins were sized for, take the brute-force path afterwards.
+    __device__ __forceinline__ void closest_hit_grid(const GridDev& G, const Ray& r, bool active, float t_min, float t_max, float& t_out,
+                                                     int& idx_out, uint32_t& n_exact) const {
+        const float a = length_squared(r.d);
+        const float big = 0x1p30f;
+        const float qx = r.o.x - G.cx, qy = r.o.y - G.cy, qz = r.o.z - G.cz;
+        // |d|^2 < 2^60: with every sphere below 2^30 (build_grid) no intermediate of the exact test overflows, so all
+        // roots are finite numbers — the condition under which the visiting order does not matter
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p60f) &&
+                          (fmaf(qx, qx, fmaf(qy, qy, qz * qz)) <= G.r_allow2) && (t_min == t_min) && (t_max == t_max);
+        const bool use = active && safe;
+        float closest = t_max;
+        int best = -1;
+        auto test = [&](int j) {
+            const float4 s = exact[j];
+            float root;
+            if (sphere_root_exact(r, a, s, t_min, closest, root) && (root < closest || j > best)) {
+                closest = root;
+                best = j;
+            }
+            ++n_exact;
+        };
+        for (int k = 0; k < G.n_always; ++k) {             // the same sphere on every lane: broadcast loads
+            const int j = static_cast<int>(G.always[k]);
+            if (use) test(j);
+        }
+        if (use) {
+            const float len = __builtin_amdgcn_sqrtf(a);
+            const float slack_t = 1.01f * G.slack * __builtin_amdgcn_rcpf(len);
+            const float tiny = 0x1p-60f * len;             // a component this small cannot leave a cell within the scene
+            const bool mx = fabsf(r.d.x) > tiny, my = fabsf(r.d.y) > tiny, mz = fabsf(r.d.z) > tiny;
+            const float inf = __builtin_inff();
+            const float ivx = mx ? 1.0f / r.d.x : inf, ivy = my ? 1.0f / r.d.y : inf, ivz = mz ? 1.0f / r.d.z : inf;
+            // clip [t_min - slack, closest + slack] against the grid box
+            float t0 = t_min - slack_t, t1 = closest + slack_t;
+            bool miss = false;
+            if (mx) { const float ta = (G.lox - r.o.x) * ivx, tb = (G.hix - r.o.x) * ivx; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.x < G.lox || r.o.x > G.hix;
+            if (my) { const float ta = (G.loy - r.o.y) * ivy, tb = (G.hiy - r.o.y) * ivy; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.y < G.loy || r.o.y > G.hiy;
+            if (mz) { const float ta = (G.loz - r.o.z) * ivz, tb = (G.hiz - r.o.z) * ivz; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.z < G.loz || r.o.z > G.hiz;
+            if (!miss && t0 <= t1 + slack_t) {
+                auto cell_of = [](float p, float lo, float ih, int n) {
+                    const float f = floorf((p - lo) * ih);
+                    return !(f >= 0.0f) ? 0 : (f > static_cast<float>(n - 1) ? n - 1 : static_cast<int>(f));   // NaN and negatives -> 0
+                };
+                int ix = cell_of(fmaf(t0, r.d.x, r.o.x), G.lox, G.ihx, G.nx);
+                int iy = cell_of(fmaf(t0, r.d.y, r.o.y), G.loy, G.ihy, G.ny);
+                int iz = cell_of(fmaf(t0, r.d.z, r.o.z), G.loz, G.ihz, G.nz);
+                const int sx = r.d.x > 0.0f ? 1 : -1, sy = r.d.y > 0.0f ? 1 : -1, sz = r.d.z > 0.0f ? 1 : -1;
+                // every step moves one cell forward along one axis, so the walk ends after at most nx + ny + nz steps
+                for (int steps = G.nx + G.ny + G.nz; steps > 0; --steps) {
+                    const int cell = (iz * G.ny + iy) * G.nx + ix;
+                    const uint32_t b = G.cell_start[cell], e = G.cell_start[cell + 1];
+                    for (uint32_t q = b; q < e; ++q) test(static_cast<int>(G.items[q]));
+                    // parameter at which the ray leaves this cell, per axis (recomputed from the cell index: no drift)
+                    const float ex = mx ? (fmaf(static_cast<float>(ix + (sx > 0 ? 1 : 0)), G.hx, G.lox) - r.o.x) * ivx : inf;
+                    const float ey = my ? (fmaf(static_cast<float>(iy + (sy > 0 ? 1 : 0)), G.hy, G.loy) - r.o.y) * ivy : inf;
+                    const float ez = mz ? (fmaf(static_cast<float>(iz + (sz > 0 ? 1 : 0)), G.hz, G.loz) - r.o.z) * ivz : inf;
+                    const float t_exit = fminf(ex, fminf(ey, ez));
+                    // nothing beyond closest (or beyond the clipped range) can win; both widened by the slack
+                    if (!(t_exit - slack_t <= fminf(closest, t1))) break;
+                    if (ex <= ey && ex <= ez) { ix += sx; if (ix < 0 || ix >= G.nx) break; }
+                    else if (ey <= ez) { iy += sy; if (iy < 0 || iy >= G.ny) break; }
+                    else { iz += sz; if (iz < 0 || iz >= G.nz) break; }
+                }
+            }
+        }
+        const bool brute = active && !safe;
+        if (wave_any(brute)) {
+            float t2;
+            int i2;
+            closest_hit(r, brute, t_min, t_max, t2, i2, n_exact);
+            if (brute) {
+                closest = t2;
+                best = i2;
+            }
+        }
         t_out = closest;
         idx_out = best;
     }

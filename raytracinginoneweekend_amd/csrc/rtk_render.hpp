@@ -23,6 +23,7 @@ struct RenderArgs {
     unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
     uint32_t* queue;             // packet counter
     unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
+    GridDev grid;                // only read by the GRID instantiation (rtk_context_set_accel)
 #ifdef RTK_HOST_EMULATION
     uint8_t* dbg_seg = nullptr;  // emulation only: [pixel][spp] segments traced per sample (work-distribution studies)
 #endif
@@ -36,7 +37,7 @@ struct RenderArgs {
 // adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
 constexpr int kDequeue = 2;      // packets a wavefront draws from the queue per atomic
 
-template <bool LDS>
+template <bool LDS, bool GRID = false>
 __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect) {
     const int lane = isect.lane;
     const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
@@ -154,7 +155,8 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         // ---- one segment: HittableList::hit (main.cpp:90) ----
         float t;
         int idx;
-        isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
+        if (GRID) isect.closest_hit_grid(A.grid, ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
+        else isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
         ++wave_passes;
         RTK_STAT_ANY(lane, pass_sky_block, alive && idx < 0);
         RTK_STAT_ANY(lane, pass_hit_block, alive && idx >= 0);

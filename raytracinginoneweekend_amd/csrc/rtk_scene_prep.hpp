@@ -16,6 +16,7 @@ namespace rtk {
 
 struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
+    std::vector<char> filterable;    // per sphere: finite, moderate, not an outlier (the filter / the grid may cull it)
     FilterBounds fb;
     int n = 0, npad = 0;
 };
@@ -83,6 +84,156 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out) {
         m1[i] = make_float4(s->metallic[i], s->ior[i], tyf, inv_v);
     }
     out.fb = fb;
+    out.filterable = filterable;
+}
+
+// ---- uniform grid (GridDev in rtk_device.hpp) -----------------------------------------------------
+struct GridHost {
+    bool usable = false;
+    const char* why = "";            // when not usable
+    GridDev dev = {};                // pointers are filled in by whoever uploads the arrays
+    std::vector<uint32_t> cell_start, items, always;
+    double mean_items_per_cell = 0.0, mean_cells_per_sphere = 0.0;
+};
+
+constexpr int kGridMaxAlways = 64;          // spheres tested for every ray; more than this: the grid is refused
+constexpr int kGridMaxCellsPerSphere = 4096;
+
+// Registers every filterable sphere in the cells its inflated box overlaps.
+// Inflation: the reference accepts a sphere (and returns a root whose point lies) up to sqrt(r^2 + E) from the centre,
+// E = 32u(|oc|^2 + r^2), u = 2^-24; |oc| <= r_allow + D/2 for origins in the ball (centre, r_allow = 0.75 D),
+// D the diagonal of the gridable spheres' bounding box.  On top of that, `slack` = 2^-14 D covers the float error of the
+// device's cell walk (positions are accurate to ~2^-22 D).
+inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g) {
+    g = GridHost();
+    const int n = s->n;
+    std::vector<int> in;
+    // The grid visits spheres in another order than the list; the reference's result is order-independent only while
+    // every root is a finite number (a NaN root makes `closest` NaN, after which HittableList.hpp:34-38 accepts
+    // whatever comes next in LIST order).  With all centres and radii finite and below 2^30, and rays as the device
+    // code admits them (|o| < 2^30, |d|^2 in (2^-80, 2^60)), no intermediate of Sphere3::hit overflows.
+    for (int i = 0; i < n; ++i) {
+        const float big = 0x1p30f;
+        if (!(std::fabs(s->cx[i]) < big && std::fabs(s->cy[i]) < big && std::fabs(s->cz[i]) < big && std::fabs(s->radius[i]) < big)) {
+            g.why = "a sphere is non-finite or beyond 2^30: results would depend on the list order";
+            return;
+        }
+    }
+    // Gridable: everything except up to 8 spheres that would blow up the grid's box (the 1000-unit ground sphere of
+    // the stock scene): largest reach from the median centre, peeled while each is more than twice the next.
+    (void)ps;
+    {
+        std::vector<float> xs(s->cx, s->cx + n), ys(s->cy, s->cy + n), zs(s->cz, s->cz + n);
+        auto median = [](std::vector<float>& v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return static_cast<double>(v[v.size() / 2]); };
+        const double mx = median(xs), my = median(ys), mz = median(zs);
+        auto reach = [&](int i) {
+            const double dx = s->cx[i] - mx, dy = s->cy[i] - my, dz = s->cz[i] - mz;
+            return std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(static_cast<double>(s->radius[i]));
+        };
+        in.resize(n);
+        for (int i = 0; i < n; ++i) in[i] = i;
+        for (int pass = 0; pass < 8 && in.size() > 1; ++pass) {
+            std::partial_sort(in.begin(), in.begin() + 2, in.end(), [&](int x, int y) { return reach(x) > reach(y); });
+            if (reach(in[0]) > 2.0 * reach(in[1])) { g.always.push_back(static_cast<uint32_t>(in[0])); in.erase(in.begin()); } else break;
+        }
+        std::sort(in.begin(), in.end());
+    }
+    if (in.empty()) { g.why = "no sphere can be put in a grid"; return; }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, r_max = 0.0;
+    for (int i : in) {
+        const double c[3] = {s->cx[i], s->cy[i], s->cz[i]}, r = std::fabs(static_cast<double>(s->radius[i]));
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k] - r); hi[k] = std::max(hi[k], c[k] + r); }
+        r_max = std::max(r_max, r);
+    }
+    const double D = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    const double centre[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    const double r_allow = 0.75 * D, oc_max = r_allow + 0.5 * D + r_max;
+    const double u = std::ldexp(1.0, -24), E = 32.0 * u * (oc_max * oc_max + r_max * r_max), slack = std::ldexp(D, -14);
+    std::vector<double> rbox(n, 0.0);
+    std::vector<double> sorted;
+    for (int i : in) {
+        const double r = std::fabs(static_cast<double>(s->radius[i]));
+        rbox[i] = (std::sqrt(r * r + E) + 2.0 * slack) * (1.0 + 1e-6);
+        sorted.push_back(rbox[i]);
+    }
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    double h0 = 2.0 * sorted[sorted.size() / 2];
+    // the grid box holds every inflated sphere box
+    double glo[3], ghi[3];
+    for (int k = 0; k < 3; ++k) { glo[k] = 1e300; ghi[k] = -1e300; }
+    for (int i : in) {
+        const double c[3] = {s->cx[i], s->cy[i], s->cz[i]};
+        for (int k = 0; k < 3; ++k) { glo[k] = std::min(glo[k], c[k] - rbox[i]); ghi[k] = std::max(ghi[k], c[k] + rbox[i]); }
+    }
+    int nc[3];
+    for (;;) {
+        double cells = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            nc[k] = static_cast<int>(std::min(1024.0, std::max(1.0, std::floor((ghi[k] - glo[k]) / h0))));
+            cells *= nc[k];
+        }
+        if (cells <= 8.0 * in.size() + 4096.0) break;
+        h0 *= 1.25;
+    }
+    // float parameters exactly as the device will use them; cell sizes rounded up so that lo + n h covers the box
+    float lof[3], hf[3], hif[3], ihf[3];
+    for (int k = 0; k < 3; ++k) {
+        lof[k] = std::nextafter(static_cast<float>(glo[k]), -std::numeric_limits<float>::infinity());
+        double h = (ghi[k] - static_cast<double>(lof[k])) / nc[k];
+        if (!(h > 0.0)) h = 1.0;
+        hf[k] = std::nextafter(static_cast<float>(h * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
+        hif[k] = std::nextafter(static_cast<float>(static_cast<double>(lof[k]) + static_cast<double>(nc[k]) * hf[k]), std::numeric_limits<float>::infinity());
+        ihf[k] = static_cast<float>(1.0 / static_cast<double>(hf[k]));
+        if (!std::isfinite(lof[k]) || !std::isfinite(hf[k]) || !std::isfinite(hif[k]) || !std::isfinite(ihf[k]) || !(ihf[k] > 0.0f)) { g.why = "scene extent is not representable"; return; }
+    }
+    auto range = [&](int i, int k, int& a, int& b) {
+        const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];
+        a = static_cast<int>(std::floor((c - rbox[i] - lof[k]) / hf[k]));
+        b = static_cast<int>(std::floor((c + rbox[i] - lof[k]) / hf[k]));
+        a = std::max(0, std::min(nc[k] - 1, a));
+        b = std::max(0, std::min(nc[k] - 1, b));
+    };
+    const size_t n_cells = static_cast<size_t>(nc[0]) * nc[1] * nc[2];
+    std::vector<uint32_t> count(n_cells + 1, 0);
+    std::vector<int> gridded;
+    for (int i : in) {
+        int a[3], b[3];
+        for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
+        const double span = static_cast<double>(b[0] - a[0] + 1) * (b[1] - a[1] + 1) * (b[2] - a[2] + 1);
+        if (span > kGridMaxCellsPerSphere) { g.always.push_back(static_cast<uint32_t>(i)); continue; }
+        gridded.push_back(i);
+        for (int z = a[2]; z <= b[2]; ++z)
+            for (int y = a[1]; y <= b[1]; ++y)
+                for (int x = a[0]; x <= b[0]; ++x) ++count[(static_cast<size_t>(z) * nc[1] + y) * nc[0] + x + 1];
+    }
+    std::sort(g.always.begin(), g.always.end());
+    if (static_cast<int>(g.always.size()) > kGridMaxAlways) { g.why = "too many spheres that a grid cannot hold (non-finite, outliers, or spanning thousands of cells)"; return; }
+    for (size_t c = 0; c < n_cells; ++c) count[c + 1] += count[c];
+    if (count[n_cells] > 0x7FFFFFFFu) { g.why = "grid too large"; return; }
+    g.cell_start = count;
+    g.items.assign(std::max<size_t>(1, count[n_cells]), 0u);
+    std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+    for (int i : gridded) {              // ascending sphere index, so every cell's items are ascending
+        int a[3], b[3];
+        for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
+        for (int z = a[2]; z <= b[2]; ++z)
+            for (int y = a[1]; y <= b[1]; ++y)
+                for (int x = a[0]; x <= b[0]; ++x) g.items[fill[(static_cast<size_t>(z) * nc[1] + y) * nc[0] + x]++] = static_cast<uint32_t>(i);
+    }
+    if (g.always.empty()) g.always.push_back(0u);      // keep the array non-empty for the upload; n_always stays 0
+    GridDev& d = g.dev;
+    d.n_always = static_cast<int32_t>(n - static_cast<int>(gridded.size()));
+    d.nx = nc[0]; d.ny = nc[1]; d.nz = nc[2];
+    d.lox = lof[0]; d.loy = lof[1]; d.loz = lof[2];
+    d.hix = hif[0]; d.hiy = hif[1]; d.hiz = hif[2];
+    d.hx = hf[0]; d.hy = hf[1]; d.hz = hf[2];
+    d.ihx = ihf[0]; d.ihy = ihf[1]; d.ihz = ihf[2];
+    d.cx = static_cast<float>(centre[0]); d.cy = static_cast<float>(centre[1]); d.cz = static_cast<float>(centre[2]);
+    d.r_allow2 = static_cast<float>(r_allow * r_allow * (1.0 - 1e-5));
+    d.slack = static_cast<float>(slack);
+    g.mean_items_per_cell = static_cast<double>(count[n_cells]) / static_cast<double>(n_cells);
+    g.mean_cells_per_sphere = gridded.empty() ? 0.0 : static_cast<double>(count[n_cells]) / static_cast<double>(gridded.size());
+    g.usable = true;
 }
 
 // The partition of a pixel's `spp` samples into runs (a lane sums one run in fp32, then adds it to the pixel's

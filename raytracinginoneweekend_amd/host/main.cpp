@@ -4,7 +4,8 @@
 // on an MI355X through librtk.so instead of the CPU loops.
 //
 // Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index, a 7th the number of
-// progressive passes the samples are split into (default 1; progress is reported after each pass).
+// progressive passes the samples are split into (default 1; progress is reported after each pass), an 8th selects how
+// the closest hit is found: 0 = the reference's list walk (default), 1 = uniform grid (same image, fewer sphere tests).
 #include "MathUtils.hpp"
 
 #include "Camera.hpp"
@@ -35,6 +36,7 @@ int main(int argc, char** argv) {
     const uint64_t seed = argc > 5 ? std::stoull(argv[5]) : 0;
     const int device = argc > 6 ? static_cast<int>(std::stoll(argv[6])) : 0;
     const int batches = argc > 7 ? static_cast<int>(std::stoll(argv[7])) : 1;
+    const int accel = argc > 8 ? static_cast<int>(std::stoll(argv[8])) : RTK_ACCEL_LIST;
 
     // World and camera (main.cpp:45-54)
     HittableList world = random_scene();
@@ -48,11 +50,11 @@ int main(int argc, char** argv) {
             std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
             if (batches <= 1) {
                 // one pass: gamma and quantisation run on the device, the file is one write
-                stats = rtiow::render_ppm(bin_file, world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device);
+                stats = rtiow::render_ppm(bin_file, world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device, accel);
             } else {
                 const rtiow::RenderResult frame = rtiow::render_image_progressive(
                     world, camera, image_width, image_height, samples_per_pixel, max_depth, batches,
-                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; }, seed, device);
+                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; }, seed, device, accel);
                 rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
                 stats = frame.stats;
             }

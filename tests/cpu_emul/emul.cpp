@@ -48,6 +48,7 @@ using namespace rtk;
 struct Emul {
     PreparedScene ps;
     SceneDev dev;
+    GridHost grid;
 };
 
 static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
@@ -70,7 +71,20 @@ void* emul_create(const rtk_scene* s) {
     Emul* e = new Emul();
     prepare_scene(s, e->ps);
     e->dev = {e->ps.filt.data(), e->ps.exact.data(), e->ps.m0.data(), e->ps.m1.data(), e->ps.n, e->ps.npad, e->ps.fb};
+    build_grid(s, e->ps, e->grid);
+    e->grid.dev.cell_start = e->grid.cell_start.data();
+    e->grid.dev.items = e->grid.items.data();
+    e->grid.dev.always = e->grid.always.data();
     return e;
+}
+
+// uniform grid as build_grid made it: info8 = usable, nx, ny, nz, n_always, items, mean items per cell x1000, mean cells per sphere x1000
+void emul_grid_info(void* h, int64_t* info8) {
+    const Emul& e = *static_cast<Emul*>(h);
+    const GridHost& g = e.grid;
+    info8[0] = g.usable; info8[1] = g.dev.nx; info8[2] = g.dev.ny; info8[3] = g.dev.nz; info8[4] = g.dev.n_always;
+    info8[5] = g.usable ? static_cast<int64_t>(g.cell_start.back()) : 0;
+    info8[6] = static_cast<int64_t>(g.mean_items_per_cell * 1000.0); info8[7] = static_cast<int64_t>(g.mean_cells_per_sphere * 1000.0);
 }
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
 
@@ -85,8 +99,9 @@ void emul_scene_info(void* h, float* bounds3, uint8_t* filterable) {
 
 // Intersector::closest_hit per ray; `flags` (optional, [n][scene size]) receives the filter's candidate flags.
 void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t_max, uint8_t* hit, int32_t* index, float* t, uint8_t* flags,
-                    uint64_t* n_exact_total, int ulp_noise) {
+                    uint64_t* n_exact_total, int ulp_noise, int accel) {
     const Emul& e = *static_cast<Emul*>(h);
+    if (accel && !e.grid.usable) accel = 0;
     rtk_shim::ulp_noise = ulp_noise;
     std::vector<uint16_t> list(kListCap * kWave);
     std::vector<float4> stage(kStageSpheres);
@@ -106,7 +121,8 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
             float tt;
             int idx;
             uint32_t ne = 0;
-            it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
+            if (accel) it.closest_hit_grid(e.grid.dev, r, active, t_min, t_max, tt, idx, ne);
+            else it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
             ne_lane[lane] = ne;
             if (active) {
                 hit[i] = idx >= 0;
@@ -159,8 +175,9 @@ void emul_philox(uint64_t seed, const uint32_t* ctr4, uint64_t n, uint32_t* out4
 
 // render_wave on `threads` CPU threads (each one "wavefront" of one lane) for rank `p->rank` of `p->world_size`;
 // writes this rank's tile sums [local tile][64][3] like rtk_render_tiles_device.  stats4 = rays, samples, exact tests, passes.
-int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* tile_sums, uint64_t* stats4, int threads, uint8_t* seg_counts) {
+int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* tile_sums, uint64_t* stats4, int threads, uint8_t* seg_counts, int accel) {
     const Emul& e = *static_cast<Emul*>(h);
+    if (accel && !e.grid.usable) accel = 0;
     const int world = p->world_size > 0 ? p->world_size : 1;
     int tw = p->tile_w, th = p->tile_h;
     if (tw == 0 && th == 0) { tw = 8; th = 8; }
@@ -191,6 +208,7 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     A.queue = &queue;
     A.stats = stats;
     A.dbg_seg = seg_counts;
+    A.grid = e.grid.dev;
     std::vector<std::thread> pool;
     for (int k = 0; k < threads; ++k)
         pool.emplace_back([&] {
@@ -198,7 +216,8 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
             std::vector<float4> stage(kStageSpheres);
             run_lanes([&](int lane) {
                 const Intersector<false> it = make_isect(e, list.data(), nullptr, lane, RTK_STAGED_LARGE ? stage.data() : nullptr);
-                render_wave<false>(A, it);
+                if (accel) render_wave<false, true>(A, it);
+                else render_wave<false, false>(A, it);
             });
             fold_stats();
         });

@@ -26,11 +26,12 @@ def lib(lanes=1):
         l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]
         l.emul_destroy.argtypes = [vp]
         l.emul_scene_info.argtypes = [vp, vp, vp]
-        l.emul_intersect.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int]
+        l.emul_intersect.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+        l.emul_grid_info.argtypes = [vp, vp]
         l.emul_scatter.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
         l.emul_primary.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, vp, C.c_uint64, vp]
         l.emul_philox.argtypes = [C.c_uint64, vp, C.c_uint64, vp]
-        l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int, vp]
+        l.emul_render_tiles.argtypes = [vp, vp, C.POINTER(rt.rtk_params), vp, vp, C.c_int, vp, C.c_int]
         l.emul_get_stats.argtypes = [vp, C.c_int]
         _libs[lanes] = l
     return _libs[lanes]
@@ -72,14 +73,20 @@ class Emul:
         self._l.emul_scene_info(self._h, b.ctypes.data, f.ctypes.data)
         return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2])}, f
 
-    def intersect(self, rays, t_min=0.001, t_max=float("inf"), want_flags=False, ulp_noise=0):
+    def grid_info(self):
+        a = np.zeros(8, np.int64)
+        self._l.emul_grid_info(self._h, a.ctypes.data)
+        return {"usable": bool(a[0]), "dims": (int(a[1]), int(a[2]), int(a[3])), "n_always": int(a[4]), "items": int(a[5]),
+                "items_per_cell": a[6] / 1000.0, "cells_per_sphere": a[7] / 1000.0}
+
+    def intersect(self, rays, t_min=0.001, t_max=float("inf"), want_flags=False, ulp_noise=0, accel=0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         n = rays.shape[0]
         hit = np.zeros(n, np.uint8); idx = np.zeros(n, np.int32); t = np.zeros(n, np.float32)
         flags = np.zeros((n, self.n), np.uint8) if want_flags else None
         ne = C.c_uint64(0)
         self._l.emul_intersect(self._h, rays.ctypes.data, n, t_min, t_max, hit.ctypes.data, idx.ctypes.data, t.ctypes.data,
-                               flags.ctypes.data if want_flags else None, C.addressof(ne), ulp_noise)
+                               flags.ctypes.data if want_flags else None, C.addressof(ne), ulp_noise, accel)
         self.last_exact = ne.value
         return (hit, idx, t, flags) if want_flags else (hit, idx, t)
 
@@ -92,20 +99,20 @@ class Emul:
         self._l.emul_scatter(self._h, rays.ctypes.data, index.ctypes.data, t.ctypes.data, u4.ctypes.data, n, out.ctypes.data)
         return out
 
-    def render_tiles(self, cam22, params, threads=8, seg_counts=None):
+    def render_tiles(self, cam22, params, threads=8, seg_counts=None, accel=0):
         nlt = rt.local_tile_count(params.width, params.height, params.rank, max(1, params.world_size), params.tile_w or 8, params.tile_h or 8)
         out = np.zeros((nlt, 64, 3), np.float32)
         st = np.zeros(4, np.uint64)
         cam = np.ascontiguousarray(cam22, np.float32)
         rc = self._l.emul_render_tiles(self._h, cam.ctypes.data, C.byref(params), out.ctypes.data, st.ctypes.data, threads,
-                                          seg_counts.ctypes.data if seg_counts is not None else None)
+                                          seg_counts.ctypes.data if seg_counts is not None else None, accel)
         assert rc == 0
         return out, {"rays": int(st[0]), "samples": int(st[1]), "exact_tests": int(st[2]), "passes": int(st[3])}
 
-    def render(self, cam22, W, H, spp, depth, seed=0, threads=8, run_len=0, tile_w=8, tile_h=8, sample_offset=0):
+    def render(self, cam22, W, H, spp, depth, seed=0, threads=8, run_len=0, tile_w=8, tile_h=8, sample_offset=0, accel=0):
         from np_mirror import deinterleave
         p = rt.make_params(W, H, spp, depth, seed, 0.001, 0, 1, tile_w, tile_h, run_len, sample_offset)
-        tiles, st = self.render_tiles(cam22, p, threads)
+        tiles, st = self.render_tiles(cam22, p, threads, accel=accel)
         return deinterleave(tiles[None], W, H, 1, tile_w, tile_h), st
 
 

@@ -1,0 +1,172 @@
+"""Uniform-grid closest hit (Intersector::closest_hit_grid) on the CPU build of the device code:
+the grid must give EXACTLY what the brute-force list walk gives — hit, closest index and t bit for bit against the
+oracle's HittableList::hit — for rays inside the scene, rays from far outside (which fall back to the list walk),
+unusual ranges, non-finite rays, tangent rays, and whole renders (same image bits, same ray count)."""
+import numpy as np
+import pytest
+
+from conftest import bits, load_golden
+import raytracinginoneweekend_amd as rt
+import emul
+from emul import Emul
+from oracle import pyoracle as po
+from test_emul_intersect import _odd_scene, tangent_rays
+
+
+def check_grid(scene, rays, t_min=0.001, t_max=np.inf, lanes=1, e=None):
+    e = e or Emul(scene, lanes=lanes)
+    assert e.grid_info()["usable"]
+    o = po.Oracle(); o.set_scene(scene)
+    ho, io, to = o.intersect(rays, t_min, t_max)
+    hit, idx, t = e.intersect(rays, t_min, t_max, accel=1)
+    nan = np.isnan(to)
+    assert np.array_equal(hit, ho) and np.array_equal(idx, io)
+    assert np.array_equal(np.isnan(t), nan) and np.array_equal(bits(t)[~nan], bits(to)[~nan])
+    return e.last_exact / max(1, len(rays))
+
+
+def scene_rays(rng, ext, m, y_hi=3.0):
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-ext, ext, m); rays[:, 1] = rng.uniform(0.01, y_hi, m); rays[:, 2] = rng.uniform(-ext, ext, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.2
+    return rays
+
+
+@pytest.mark.parametrize("batch", ["primary", "secondary", "tertiary", "random", "grazing", "inside", "degenerate"])
+def test_grid_on_reference_fixtures(stock_scene_golden, batch):
+    z = load_golden("rays_stock.npz")
+    e = Emul(stock_scene_golden)
+    hit, idx, t = e.intersect(z[batch + "_rays"], accel=1)
+    want_t = z[batch + "_t"]
+    nan = np.isnan(want_t)
+    assert np.array_equal(hit, z[batch + "_hit"]) and np.array_equal(idx, z[batch + "_index"])
+    assert np.array_equal(np.isnan(t), nan) and np.array_equal(bits(t)[~nan], bits(want_t)[~nan])
+    if batch == "primary":
+        assert e.last_exact / len(hit) < 12        # a few cells' worth of spheres instead of 484
+
+
+def test_grid_ties(stock_scene_golden):
+    z = load_golden("rays_ties.npz")
+    from test_oracle_golden import ties_scene
+    s = ties_scene(z)
+    e = Emul(s)
+    if e.grid_info()["usable"]:
+        hit, idx, t = e.intersect(z["rays"], accel=1)
+        assert np.array_equal(hit, z["hit"]) and np.array_equal(idx, z["index"]) and np.array_equal(bits(t), bits(z["t"]))
+
+
+@pytest.mark.parametrize("k,m", [(16, 4000), (50, 4000), (135, 2500)])
+def test_grid_large_scenes(k, m):
+    """BASELINE.json config 4: 1k / 10k / 73k spheres."""
+    s = rt.scaled_scene(k=k)
+    rng = np.random.default_rng(k)
+    per_ray = check_grid(s, scene_rays(rng, float(k), m))
+    assert per_ray < 0.02 * len(s["cx"]) + 30
+    check_grid(s, tangent_rays(rng, s, 1500, 0.3, 2.0 * k, 1e-5, first=1))
+
+
+def test_grid_camera_rays_and_far_origins():
+    """Rays from the stock camera, from 3x the scene size away (still inside the grid's ball) and from 50x away
+    (outside: the lane takes the list walk; the reference 'hits' spheres there that the ray misses geometrically)."""
+    s = rt.scaled_scene(k=30)
+    rng = np.random.default_rng(5)
+    m = 1500
+    for dist in (0.8, 3.0, 50.0):
+        o = rng.normal(size=(m, 3)); o /= np.linalg.norm(o, axis=1, keepdims=True); o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.02
+        o *= dist * 30.0
+        target = np.stack([rng.uniform(-30, 30, m), rng.uniform(0, 1, m), rng.uniform(-30, 30, m)], 1)
+        rays = np.concatenate([o, target - o], 1).astype(np.float32)
+        check_grid(s, rays)
+
+
+@pytest.mark.parametrize("t_min,t_max", [(0.0, np.inf), (-50.0, 3.0), (2.0, 1.0), (0.001, np.nan), (np.nan, np.inf), (-np.inf, np.inf), (5.0, 40.0), (1e-30, 1e30)])
+def test_grid_unusual_ranges(t_min, t_max):
+    s = rt.scaled_scene(k=20)
+    rng = np.random.default_rng(7)
+    check_grid(s, scene_rays(rng, 20.0, 2500), t_min, t_max)
+
+
+def test_grid_degenerate_rays_and_scenes():
+    rng = np.random.default_rng(3)
+    s = _odd_scene(rng, 300)
+    s["radius"][3] = -0.7; s["radius"][5] = 3e4; s["cx"][7] = 4e5; s["radius"][9] = 1e-30; s["radius"][27] = 500.0; s["radius"][13] = 0.0
+    m = 3000
+    rays = np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    rays[::17, 3:6] = 0.0                      # zero-length directions
+    rays[::19, 4] = np.nan
+    rays[::23, 0] = np.inf
+    rays[::29, 3] = 0.0; rays[::29, 5] = 0.0   # axis-parallel
+    rays[::31, 3:6] *= 1e-25                   # tiny directions
+    rays[::37, 3:6] *= 1e25
+    e = Emul(s)
+    assert e.grid_info()["n_always"] == 3          # radius 3e4, centre at 4e5, radius 500
+    check_grid(s, rays, e=e)
+    # axis-parallel rays that start exactly on cell boundaries
+    g = e.grid_info()
+    rays2 = np.zeros((600, 6), np.float32)
+    rays2[:, 0:3] = np.round(rng.uniform(-12, 12, (600, 3)) * 4) / 4
+    rays2[np.arange(600), 3 + rng.integers(0, 3, 600)] = rng.choice([-1.0, 1.0], 600)
+    check_grid(s, rays2, e=e)
+
+
+@pytest.mark.parametrize("scale,offset", [(1e-3, (0, 0, 0)), (1e3, (0, 0, 0)), (1.0, (1e4, -3e3, 500)), (1e-6, (0, 0, 0)), (1e6, (0, 0, 0))])
+def test_grid_scaled_and_translated(scale, offset):
+    rng = np.random.default_rng(11)
+    s = _odd_scene(rng, 400, scale, offset)
+    m = 3000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-12, 12, (m, 3)) * scale + np.array(offset)
+    rays[:, 3:6] = rng.normal(size=(m, 3)) * scale
+    check_grid(s, rays)
+
+
+@pytest.mark.parametrize("what", ["nan", "inf", "many_outliers"])
+def test_grid_refused_falls_back_to_the_list_walk(what):
+    """A NaN root makes the reference's result depend on the LIST order (closest becomes NaN and everything after it is
+    accepted), so scenes with non-finite spheres are never put in a grid.  A scene half made of giant spheres gets a
+    coarse grid; either way the result is the list walk's."""
+    rng = np.random.default_rng(2)
+    s = _odd_scene(rng, 200)
+    if what == "nan":
+        s["cx"][7] = np.nan
+    elif what == "inf":
+        s["radius"][5] = np.inf
+    else:
+        s["radius"][:100] = rng.uniform(3e3, 3e4, 100).astype(np.float32)      # each would span millions of cells
+    e = Emul(s)
+    assert e.grid_info()["usable"] == (what == "many_outliers")      # a coarse grid is still a correct one
+    rays = np.concatenate([rng.uniform(-12, 12, (500, 3)), rng.normal(size=(500, 3))], 1).astype(np.float32)
+    o = po.Oracle(); o.set_scene(s)
+    ho, io, to = o.intersect(rays, 0.001, np.inf)
+    hit, idx, t = e.intersect(rays, accel=1)        # falls back to the list walk
+    assert np.array_equal(hit, ho) and np.array_equal(idx, io)
+
+
+def test_grid_render_is_bit_identical_to_list_walk(stock_scene_golden):
+    """Same intersections -> same paths -> the same image bits and the same ray count, with ~100x fewer sphere tests."""
+    e = Emul(stock_scene_golden)
+    cam = rt.stock_camera(1.5)
+    a, sa = e.render(cam, 60, 40, 8, 50, seed=3, threads=4)
+    b, sb = e.render(cam, 60, 40, 8, 50, seed=3, threads=4, accel=1)
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+    s = rt.scaled_scene(k=40)
+    e = Emul(s)
+    a, sa = e.render(cam, 32, 20, 2, 50, seed=1, threads=8)
+    b, sb = e.render(cam, 32, 20, 2, 50, seed=1, threads=8, accel=1)
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+
+
+def test_grid_in_64_lane_waves(stock_scene_golden):
+    """Divergent per-lane walks inside a wave, and the wave-level fallback vote for non-finite lanes."""
+    z = load_golden("rays_stock.npz")
+    e = Emul(stock_scene_golden, lanes=64)
+    rays = np.concatenate([z["primary_rays"][:500], z["degenerate_rays"], z["inside_rays"][:300]])
+    want = [np.concatenate([z["primary_" + k][:500], z["degenerate_" + k], z["inside_" + k][:300]]) for k in ("hit", "index", "t")]
+    hit, idx, t = e.intersect(rays, accel=1)
+    nan = np.isnan(want[2])
+    assert np.array_equal(hit, want[0]) and np.array_equal(idx, want[1]) and np.array_equal(bits(t)[~nan], bits(want[2])[~nan])
+    cam = rt.stock_camera(37 / 23)
+    a, sa = Emul(stock_scene_golden).render(cam, 37, 23, 6, 50, seed=5, threads=2)
+    b, sb = e.render(cam, 37, 23, 6, 50, seed=5, threads=3, accel=1)
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+    assert emul.lib(64).emul_simt_error() == 0
