@@ -24,7 +24,8 @@ do
   echo "== pmc pass $i: $PMC"
   timeout -s KILL 120 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -o pmc$i -- $CMD > $OUT/pmc$i.log 2>&1
   rc=$?
-  if [ $rc -ne 0 ]; then echo "pass $i rc=$rc"; tail -3 $OUT/pmc$i.log; fi
   if grep -q "error code 38" $OUT/pmc$i.log; then echo "pass $i: too many counters"; fi
+  # a failed pass may have left the GPU in a bad state: start nothing more on it in this call
+  if [ $rc -ne 0 ]; then echo "pass $i rc=$rc; stopping"; tail -3 $OUT/pmc$i.log; exit 1; fi
 done
 find $OUT -name "*.csv" | head -40
