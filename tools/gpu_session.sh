@@ -36,6 +36,7 @@ case "$STAGE" in
     bash tools/profile.sh "$TAG" || exit 1 ;;
   config4)
     step 300 gpurun_out/${TAG}_config4_list.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
+    step 300 gpurun_out/${TAG}_config4_staged.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_staged.so python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
     step 300 gpurun_out/${TAG}_config4_grid.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline --accel grid
     step 300 gpurun_out/${TAG}_stock_grid.json python bench.py --accel grid --no-cpu-baseline ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
