@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=(1, 2),
+                    help="2: consecutive frames alternate between two contexts/streams so that the tail of one frame's persistent kernel overlaps the "
+                         "start of the next (throughput experiment, DESIGN.md §7; per-kernel event times then include the overlap)")
     ap.add_argument("--scene-k", type=int, default=0,
                     help="0: the stock 484-sphere scene (the metric's workload).  K > 0: BASELINE.json config 4, the same generator on a [-K,K)^2 grid (K=50: 10k spheres)")
     ap.add_argument("--accel", choices=("list", "grid"), default="list",
@@ -113,9 +116,17 @@ def main():
         raise SystemExit("the grid was refused for this scene: " + rt.lib().rtk_last_error().decode())
     cam = rt.stock_camera(float(np.float32(args.width) / np.float32(args.height)))
     sr = ShardedRenderer(ctx, args.width, args.height, rank, world, device)
+    ctxs, srs = [ctx], [sr]
+    for _ in range(1, args.frames_in_flight):
+        c2 = rt.Context(local_rank)
+        c2.set_scene(scene)
+        if args.accel == "grid":
+            c2.set_accel(rt.ACCEL_GRID)
+        ctxs.append(c2)
+        srs.append(ShardedRenderer(c2, args.width, args.height, rank, world, device))
 
     def step(i):
-        sr.render(cam, args.spp, args.depth, seed=i)
+        srs[i % len(srs)].render(cam, args.spp, args.depth, seed=i)
 
     def fence():
         torch.cuda.synchronize()
@@ -126,7 +137,8 @@ def main():
     for i in range(args.warmup):
         step(1000 + i)
     fence()
-    ctx.reset_stats()
+    for c in ctxs:
+        c.reset_stats()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -134,6 +146,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st = ctx.get_stats()
+    for c in ctxs[1:]:                       # counters of the other frames in flight
+        o = c.get_stats()
+        for key in ("rays", "samples", "sphere_tests", "exact_tests", "lane_slots", "kernel_ms", "frames", "frames_timed"):
+            st[key] += o[key]
 
     tot = torch.tensor([float(st["rays"]), float(st["samples"]), float(st["kernel_ms"]), float(st["frames_timed"]), float(st["lane_slots"]),
                         float(st["exact_tests"])], dtype=torch.float64, device=device)
@@ -173,7 +189,7 @@ def main():
                                    f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}, stock camera, closest hit by " +
                                    ("uniform grid (bit-identical image, fewer sphere tests; not the roofline's algorithm)" if args.accel == "grid" else "list walk"),
                        "sharding": f"8x8-pixel tiles interleaved over {world} rank(s), one all_gather of fp32 tile sums per frame",
-                       "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max},
+                       "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max, "frames_in_flight": args.frames_in_flight},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays,
@@ -189,8 +205,9 @@ def main():
         print(json.dumps(out), flush=True)
     # tear down in order: the context must not outlive the torch stream it was pointed at
     torch.cuda.synchronize()
-    ctx.set_stream(0)
-    ctx.close()
+    for c in ctxs:
+        c.set_stream(0)
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

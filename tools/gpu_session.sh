@@ -9,7 +9,8 @@
 #   rates    issue rates of candidate filter instructions                  -> gpurun_out/<tag>_valu_rates.txt
 #   ab       interleaved A/B of the kernel variants at 100 spp             -> gpurun_out/<tag>_ab.txt
 #   profile  rocprofv3 kernel trace + PMC passes (tools/profile.sh)        -> gpurun_out/prof_<tag>/
-#   config4  list walk vs uniform grid on the 10k-sphere scene             -> gpurun_out/<tag>_config4.txt
+#   config4  list walk vs uniform grid on the 10k-sphere scene             -> gpurun_out/<tag>_config4_*.json
+#   overlap  one vs two frames in flight, full frame and an eighth of it   -> gpurun_out/<tag>_overlap*.json
 set -u
 STAGE=${1:?stage}
 TAG=${2:-r02}
@@ -39,6 +40,11 @@ case "$STAGE" in
     step 300 gpurun_out/${TAG}_config4_staged.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_staged.so python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
     step 300 gpurun_out/${TAG}_config4_grid.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline --accel grid
     step 300 gpurun_out/${TAG}_stock_grid.json python bench.py --accel grid --no-cpu-baseline ;;
+  overlap)
+    step 300 gpurun_out/${TAG}_overlap1.json python bench.py --no-cpu-baseline
+    step 300 gpurun_out/${TAG}_overlap2.json python bench.py --no-cpu-baseline --frames-in-flight 2
+    step 300 gpurun_out/${TAG}_overlap2_small.json python bench.py --no-cpu-baseline --frames-in-flight 2 --width 424 --height 283 --steps 40   # one eighth of the frame: the per-GPU share at N = 8
+    step 300 gpurun_out/${TAG}_overlap1_small.json python bench.py --no-cpu-baseline --width 424 --height 283 --steps 40 ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
 echo "stage $STAGE done"
