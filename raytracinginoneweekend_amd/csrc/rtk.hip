@@ -54,6 +54,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
         it.filt = sc.filt;
         it.exact = sc.exact;
     }
+    it.always = sc.always_mask;
     it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
 #if RTK_STAGED_LARGE
     if (!LDS) it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
@@ -224,6 +225,7 @@ struct rtk_context {
     SceneDev scene = {};
     bool have_scene = false;
     DevBuf filt, exact, mat0, mat1;
+    DevBuf amask;        // RTK_FILTER_FORM == 2: per-word masks of the spheres the filter must always pass
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
     std::vector<uint2> runs_host;
     int runs_key[4] = {-1, -1, -1, -1};
@@ -331,7 +333,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->amask, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -378,6 +380,14 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     HIP_TRY(hipMemcpy(c->mat1.p, m1.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
                 static_cast<const float4*>(c->mat1.p), n, npad, fb};
+#if RTK_FILTER_FORM == 2
+    if (fb.f16_ok) {
+        if (ps.always_mask.size() != static_cast<size_t>(npad / 32)) return fail(RTK_ERR_HIP, "internal: always-mask size");
+        HIP_TRY(c->amask.reserve(ps.always_mask.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->amask.p, ps.always_mask.data(), ps.always_mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->scene.always_mask = static_cast<const uint32_t*>(c->amask.p);
+    }
+#endif
     c->have_scene = true;
     c->h_cx.assign(s->cx, s->cx + n); c->h_cy.assign(s->cy, s->cy + n); c->h_cz.assign(s->cz, s->cz + n); c->h_radius.assign(s->radius, s->radius + n);
     c->grid_ok = false;

@@ -114,7 +114,27 @@ struct FilterBounds {
     float c_max;     // max |C| + |r|
     float r_max2;    // max r^2
     float r_min;     // min |r|
+    // RTK_FILTER_FORM == 2 (packed-f16 projection filter).  Filter space = (x - cen) * scale, scale a power of two
+    // that puts the scene's reach into [2^7, 2^8).  f16_ok == 0: this scene's `filt` holds the f32 records of form 1.
+    int32_t f16_ok;
+    float cen[3];
+    float scale;
+    int32_t ax[3];       // coordinate order of the f16 chain: ax[0] (largest extent) first ... ax[2] (smallest) last
+    float cmax_s[3];     // per chain position: max |c_hat| over the filterable spheres, filter space
+    float c_max_s;       // max |C'| + |r|, filter space
+    float r_min_s;       // min |r|, filter space
+    float r_max2_s;      // max r^2, filter space
 };
+
+// Packed binary16 pairs for the form-2 filter.  (The CPU build models them in tests/cpu_emul/rtk_host_shim.hpp.)
+#ifndef RTK_HOST_EMULATION
+typedef _Float16 H2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ H2 h2_splat(float v) { const _Float16 h = static_cast<_Float16>(v); return H2{h, h}; }   // v_cvt_f16_f32: nearest even
+__device__ __forceinline__ H2 h2_from_bits(float bits) { return __builtin_bit_cast(H2, bits); }
+__device__ __forceinline__ uint32_t h2_bits(H2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ float h2_lo(H2 v) { return static_cast<float>(v.x); }
+__device__ __forceinline__ H2 h2_fma(H2 a, H2 b, H2 c) { return __builtin_elementwise_fma(a, b, c); }                // v_pk_fma_f16
+#endif
 
 struct SceneDev {
     const float4* filt;   // [npad] cx, cy, cz, r^2 (1+k): filter operands; pads never pass
@@ -124,6 +144,7 @@ struct SceneDev {
     int32_t n;
     int32_t npad;         // n rounded up to a multiple of 32
     FilterBounds fb;
+    const uint32_t* always_mask = nullptr;   // RTK_FILTER_FORM == 2: [npad / 32] per word, MSB = first sphere: spheres the filter must pass
 };
 
 struct CameraDev {
@@ -173,7 +194,8 @@ __device__ __forceinline__ bool sphere_root_exact(const Ray& r, float a, float4 
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
 #ifndef RTK_FILTER_FORM
-#define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test)
+#define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test),
+                               // 2 (experiment build): packed-f16 projection form (5 / test) where the scene allows, else form 1
 #endif
 
 // RTK_SMEM=1 (experiment build, NOT the shipped default, never timed yet): the filter reads its sphere operands
@@ -189,6 +211,13 @@ typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
 #define RTK_FILT_LOAD(i) (reinterpret_cast<rtk_const_f4_ptr>(reinterpret_cast<uintptr_t>(filt_global))[i])
 #else
 #define RTK_FILT_LOAD(i) (filt[i])
+#endif
+
+// Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
+#ifdef RTK_HOST_EMULATION
+#define RTK_SCHED_BARRIER() ((void)0)
+#else
+#define RTK_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 // RTK_STAGED_LARGE=1 (experiment build, default off until it has run on a GPU): scenes beyond kMaxLdsSpheres stream
@@ -232,6 +261,7 @@ struct Intersector {
     const float4* filt;    // LDS or global
     const float4* filt_global;   // always the global-memory copy (RTK_SMEM reads through it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
+    const uint32_t* always = nullptr;   // RTK_FILTER_FORM == 2: SceneDev::always_mask (global; read with wave-uniform indices)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
     float4* stage = nullptr;     // RTK_STAGED_LARGE: this wave's LDS chunk of kStageSpheres filter operands
     FilterBounds fb;
@@ -267,7 +297,23 @@ struct Intersector {
 #else
         float e1x, e1y, e1z, ns1, e2x, e2y, e2z, ns2;
 #endif
+#if RTK_FILTER_FORM == 2
+        H2 a1, b1, c1, n1, a2, b2, c2, n2;     // e1 / e2 components in chain order and -o.e, shrunk by g, each in both halves
+#endif
     };
+
+#if RTK_FILTER_FORM == 2
+    // Packed-f16 form: TWO spheres per register (one in each half), 10 instructions per pair = 5 per test:
+    // 2 x 3 v_pk_fma_f16 for the two projections, 2 v_pk_fma_f16 for p1^2 + p2^2 - rho^2, then the two sign bits
+    // (bits 31 and 15) are rotated to their place in the word's mask and merged (v_alignbit_b32, v_and_or_b32).
+    // rec = (c_hat[ax0], c_hat[ax1], c_hat[ax2], -rho^2), each dword holding the value for both spheres of the pair.
+    static __device__ __forceinline__ uint32_t filter_pair_f16(const FilterRay& f, float rx, float ry, float rz, float rw) {
+        const H2 ca = h2_from_bits(rx), cb = h2_from_bits(ry), cc = h2_from_bits(rz), k = h2_from_bits(rw);
+        const H2 p1 = h2_fma(cc, f.c1, h2_fma(cb, f.b1, h2_fma(ca, f.a1, f.n1)));
+        const H2 p2 = h2_fma(cc, f.c2, h2_fma(cb, f.b2, h2_fma(ca, f.a2, f.n2)));
+        return h2_bits(h2_fma(p2, p2, h2_fma(p1, p1, k)));
+    }
+#endif
 
     // One ray-sphere filter test; shifts the result bit into `m` (form 0: 1 = certainly missed, form 1: 1 = candidate).
     static __device__ __forceinline__ void filter_one(const FilterRay& f, float sx, float sy, float sz, float sw, uint32_t& m) {
@@ -292,7 +338,7 @@ struct Intersector {
         // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
         // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
         const float big = 0x1p30f;
-        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+        bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
         FilterRay f;
         const float inv_len = __builtin_amdgcn_rsqf(a);
 #if RTK_FILTER_FORM == 0
@@ -304,18 +350,50 @@ struct Intersector {
         // a sphere can only be hit if its centre, projected on that plane, lies within r of the ray.
         // The projected distances are shrunk by g < 1 so that everything the reference's own rounding could
         // still accept (E) and this filter's evaluation error (dp) stay inside r.
+        const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
+        const float sg = copysignf(1.0f, dz);
+        const float aa = -__builtin_amdgcn_rcpf(sg + dz);
+        const float bb = dx * dy * aa;
+        const float u1x = fmaf(sg * dx, dx * aa, 1.0f), u1y = sg * bb, u1z = -sg * dx;     // unshrunk basis
+        const float u2x = bb, u2y = fmaf(dy, dy * aa, sg), u2z = -dy;
+#if RTK_FILTER_FORM == 2
+        if (fb.f16_ok) {
+            // Filter space: recentred and scaled by a power of two (binary16 has 5 exponent bits).
+            const float ox = (r.o.x - fb.cen[0]) * fb.scale, oy = (r.o.y - fb.cen[1]) * fb.scale, oz = (r.o.z - fb.cen[2]) * fb.scale;
+            const float o_len = __builtin_amdgcn_sqrtf(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));
+            const float M = o_len + fb.c_max_s;
+            const float E = 0x1p-19f * fmaf(M, M, fb.r_max2_s);
+            const float dp = 0x1p-19f * M;
+            // coordinates in chain order (a scene-wide permutation: largest extent first, smallest last)
+            auto pick = [](float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); };
+            const float a1 = pick(u1x, u1y, u1z, fb.ax[0]), b1 = pick(u1x, u1y, u1z, fb.ax[1]), c1 = pick(u1x, u1y, u1z, fb.ax[2]);
+            const float a2 = pick(u2x, u2y, u2z, fb.ax[0]), b2 = pick(u2x, u2y, u2z, fb.ax[1]), c2 = pick(u2x, u2y, u2z, fb.ax[2]);
+            const float oa = pick(ox, oy, oz, fb.ax[0]), ob = pick(ox, oy, oz, fb.ax[1]), oc = pick(ox, oy, oz, fb.ax[2]);
+            // binary16 error of one projected coordinate of a sphere that matters (|p| <= r~), per unit of g
+            // (DESIGN.md §4.1 form 2): basis quantisation u M, rounding of -o.e, and the three chain roundings
+            // u (3|p| + 2|t_last| + |t_mid|); the 3|p| part, subnormal steps and the roundings of p^2 - rho^2 are
+            // inside the per-sphere rho.
+            const float n1 = fabsf(fmaf(oc, c1, fmaf(ob, b1, oa * a1))), n2 = fabsf(fmaf(oc, c2, fmaf(ob, b2, oa * a2)));
+            const float k1 = n1 + fmaf(2.0f * fb.cmax_s[2], fabsf(c1), fb.cmax_s[1] * fabsf(b1));
+            const float k2 = n2 + fmaf(2.0f * fb.cmax_s[2], fabsf(c2), fb.cmax_s[1] * fabsf(b2));
+            const float d16 = (1.03f * 0x1p-11f) * (M + fmaxf(k1, k2));
+            const float g = fb.r_min_s * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min_s, fb.r_min_s, E)) + 2.0f * (dp + d16)) * (1.0f - 0x1p-16f);
+            safe = safe && (o_len < 0x1p15f) && (g > 0x1p-6f);      // |o.e| stays below binary16's 65504; below that g the margins stop scaling with g
+            f.a1 = h2_splat(g * a1); f.b1 = h2_splat(g * b1); f.c1 = h2_splat(g * c1);
+            f.a2 = h2_splat(g * a2); f.b2 = h2_splat(g * b2); f.c2 = h2_splat(g * c2);
+            // -o.e against the QUANTISED basis, so that only its own rounding to binary16 remains
+            f.n1 = h2_splat(-fmaf(oc, h2_lo(f.c1), fmaf(ob, h2_lo(f.b1), oa * h2_lo(f.a1))));
+            f.n2 = h2_splat(-fmaf(oc, h2_lo(f.c2), fmaf(ob, h2_lo(f.b2), oa * h2_lo(f.a2))));
+        } else
+#endif
         {
-            const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
-            const float sg = copysignf(1.0f, dz);
-            const float aa = -__builtin_amdgcn_rcpf(sg + dz);
-            const float bb = dx * dy * aa;
             const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
             const float M = o_len + fb.c_max;
             const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
             const float dp = 0x1p-19f * M;
             const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
-            f.e1x = g * fmaf(sg * dx, dx * aa, 1.0f); f.e1y = g * (sg * bb); f.e1z = g * (-sg * dx);
-            f.e2x = g * bb; f.e2y = g * fmaf(dy, dy * aa, sg); f.e2z = g * (-dy);
+            f.e1x = g * u1x; f.e1y = g * u1y; f.e1z = g * u1z;
+            f.e2x = g * u2x; f.e2y = g * u2y; f.e2z = g * u2z;
             f.ns1 = -fmaf(r.o.z, f.e1z, fmaf(r.o.y, f.e1y, r.o.x * f.e1x));
             f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
         }
@@ -386,6 +464,70 @@ struct Intersector {
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
+#if RTK_FILTER_FORM == 2
+        // Pair records: word w of 32 spheres owns records [16 w, 16 w + 16); in a word of `cnt` spheres, pair k holds
+        // sphere k in its HIGH halves and sphere np + k in its LOW halves, np = ceil(cnt / 2) — so that after np steps the
+        // mask has the first np spheres in bits 31.. and the rest in bits 15.. (for a full word that IS the usual
+        // MSB-first order; a partial last word shifts its low half up).
+        auto scan_pairs = [&](auto&& loadq, int count) {
+            const int full = count >> 5, rem = count & 31;
+            for (int w = 0; w < full; ++w) {
+                if (w * 32 - list_base > 65535 - 64) {
+                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                    list_base = w * 32;
+                }
+                uint32_t m = always[w];
+                // four pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one between
+                // them on gfx950), with the next four records already requested
+                auto q0 = loadq(w * 16 + 0), q1 = loadq(w * 16 + 1), q2 = loadq(w * 16 + 2), q3 = loadq(w * 16 + 3);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nx = w * 16 + (g < 3 ? 4 * (g + 1) : 4 * g);      // last group: re-reads itself, never beyond the word
+                    const auto n0 = loadq(nx + 0), n1 = loadq(nx + 1), n2 = loadq(nx + 2), n3 = loadq(nx + 3);
+                    RTK_SCHED_BARRIER();      // keep these four requests ahead of the arithmetic on the previous four
+                    H2 x0 = h2_fma(h2_from_bits(q0.x), f.a1, f.n1), x1 = h2_fma(h2_from_bits(q1.x), f.a1, f.n1);
+                    H2 x2 = h2_fma(h2_from_bits(q2.x), f.a1, f.n1), x3 = h2_fma(h2_from_bits(q3.x), f.a1, f.n1);
+                    H2 y0 = h2_fma(h2_from_bits(q0.x), f.a2, f.n2), y1 = h2_fma(h2_from_bits(q1.x), f.a2, f.n2);
+                    H2 y2 = h2_fma(h2_from_bits(q2.x), f.a2, f.n2), y3 = h2_fma(h2_from_bits(q3.x), f.a2, f.n2);
+                    x0 = h2_fma(h2_from_bits(q0.y), f.b1, x0); x1 = h2_fma(h2_from_bits(q1.y), f.b1, x1);
+                    x2 = h2_fma(h2_from_bits(q2.y), f.b1, x2); x3 = h2_fma(h2_from_bits(q3.y), f.b1, x3);
+                    y0 = h2_fma(h2_from_bits(q0.y), f.b2, y0); y1 = h2_fma(h2_from_bits(q1.y), f.b2, y1);
+                    y2 = h2_fma(h2_from_bits(q2.y), f.b2, y2); y3 = h2_fma(h2_from_bits(q3.y), f.b2, y3);
+                    x0 = h2_fma(h2_from_bits(q0.z), f.c1, x0); x1 = h2_fma(h2_from_bits(q1.z), f.c1, x1);
+                    x2 = h2_fma(h2_from_bits(q2.z), f.c1, x2); x3 = h2_fma(h2_from_bits(q3.z), f.c1, x3);
+                    y0 = h2_fma(h2_from_bits(q0.z), f.c2, y0); y1 = h2_fma(h2_from_bits(q1.z), f.c2, y1);
+                    y2 = h2_fma(h2_from_bits(q2.z), f.c2, y2); y3 = h2_fma(h2_from_bits(q3.z), f.c2, y3);
+                    x0 = h2_fma(x0, x0, h2_from_bits(q0.w)); x1 = h2_fma(x1, x1, h2_from_bits(q1.w));
+                    x2 = h2_fma(x2, x2, h2_from_bits(q2.w)); x3 = h2_fma(x3, x3, h2_from_bits(q3.w));
+                    const uint32_t d0 = h2_bits(h2_fma(y0, y0, x0)), d1 = h2_bits(h2_fma(y1, y1, x1));
+                    const uint32_t d2 = h2_bits(h2_fma(y2, y2, x2)), d3 = h2_bits(h2_fma(y3, y3, x3));
+                    const int k = 4 * g;
+                    m |= (d0 >> k) & (0x80008000u >> k);
+                    m |= (d1 >> (k + 1)) & (0x80008000u >> (k + 1));
+                    m |= (d2 >> (k + 2)) & (0x80008000u >> (k + 2));
+                    m |= (d3 >> (k + 3)) & (0x80008000u >> (k + 3));
+                    q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+                }
+                RTK_STAT(lane, filter_words);
+                emit(w * 32, to_cand(m, 0xFFFFFFFFu));
+            }
+            if (rem) {
+                const int np = (rem + 1) >> 1;
+                uint32_t m = 0;
+#pragma unroll 2
+                for (int k = 0; k < np; ++k) {
+                    const auto q = loadq(full * 16 + k);
+                    const uint32_t d = filter_pair_f16(f, q.x, q.y, q.z, q.w);
+                    m |= __builtin_amdgcn_alignbit(d, d, k) & (0x80008000u >> k);
+                }
+                m = ((m & 0xFFFF0000u) | ((m & 0xFFFFu) << (16 - np))) | always[full];
+                emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+            }
+        };
+        if (fb.f16_ok) {
+            scan_pairs([&](int j) { return RTK_FILT_LOAD(j); }, n);
+        } else
+#endif
 #if RTK_STAGED_LARGE
         if (!LDS) {
             // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced

@@ -56,6 +56,7 @@ static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg
     it.filt = e.ps.filt.data();
     it.filt_global = e.ps.filt.data();
     it.exact = e.ps.exact.data();
+    it.always = e.ps.always_mask.empty() ? nullptr : e.ps.always_mask.data();
     it.list = list;
     it.fb = e.ps.fb;
     it.n = e.ps.n;

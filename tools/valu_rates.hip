@@ -24,8 +24,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum Op { FMA_F32, FMA_F32_SGPR, PK_FMA_F32, PK_FMA_F16, DOT2_F32_F16, DOT2C_F32_F16, DOT2_F32_BF16, ALIGNBIT, MIX_FORM1, MIX_FORM2, N_OPS };
 static const char* kNames[N_OPS] = {"v_fma_f32", "v_fma_f32 (SGPR src)", "v_pk_fma_f32", "v_pk_fma_f16", "v_dot2_f32_f16", "v_dot2c_f32_f16",
-                                    "v_dot2_f32_bf16", "v_alignbit_b32", "form 1 body: 8 fma + alignbit", "form 2 body: 4 fma + 2 dot2 + alignbit"};
-static const int kInstrPerRound[N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 72, 56};
+                                    "v_dot2_f32_bf16", "v_alignbit_b32", "form 1 body: 8 fma + alignbit (per sphere)", "form 2 body: 8 pk_fma_f16 + shift + and (per PAIR)"};
+static const int kInstrPerRound[N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 72, 80};
 
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float seed_s) {
@@ -72,16 +72,28 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float 
             }
         }
         if (OP == MIX_FORM2) {
+            // the packed-f16 filter body (RTK_FILTER_FORM=2) for 8 PAIRS = 16 spheres, four pairs stage by stage
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float p1 = a[j], p2 = a[(j + 1) & 7], d;
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(p1) : "v"(b), "v"(c));
-                asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(p1) : "v"(c), "v"(b));
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(p2) : "v"(b), "v"(c));
-                asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(p2) : "v"(c), "v"(b));
-                asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(d) : "v"(p1), "v"(c));
-                asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(d) : "v"(p2));
-                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(m) : "v"(d));
+            for (int h = 0; h < 2; ++h) {
+                float* x = a;          // the eight accumulators stand in for four (p1, p2) pairs of chains
+                float* y = a + 4;
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(x[j]) : "v"(b), "v"(c));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(y[j]) : "v"(c), "v"(b));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("v_pk_fma_f16 %0, %0, %0, %1" : "+v"(x[j]) : "v"(c));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("v_pk_fma_f16 %0, %1, %1, %0" : "+v"(x[j]) : "v"(y[j]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned t;
+                    asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(t) : "v"(x[j]));
+                    asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(m) : "v"(t), "v"(0x10001000u));
+                }
             }
         }
     }
@@ -138,7 +150,7 @@ int main(int argc, char** argv) {
     for (int op = 0; op < N_OPS; ++op) {
         const double ns = ms[op] * 1e6 / (static_cast<double>(iters) * kInstrPerRound[op] * waves_per_simd);
         std::printf("%-42s %8.3f ms   %7.4f ns per wave-instruction per SIMD   x%.2f of v_fma_f32%s\n", kNames[op], ms[op], ns, ns / base,
-                    (op == MIX_FORM1 || op == MIX_FORM2) ? "  (one round = 8 spheres)" : "");
+                    op == MIX_FORM1 ? "  (one round = 8 spheres)" : op == MIX_FORM2 ? "  (one round = 16 spheres)" : "");
     }
     CHECK(hipFree(d_out));
     return 0;
