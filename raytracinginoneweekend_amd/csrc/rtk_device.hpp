@@ -303,6 +303,10 @@ struct Intersector {
     };
 
 #if RTK_FILTER_FORM == 2
+#ifndef RTK_PAIR_GROUP
+#define RTK_PAIR_GROUP 2
+#endif
+    static constexpr int kPairGroup = RTK_PAIR_GROUP;     // pairs processed together (2 or 4; more = more registers)
     // Packed-f16 form: TWO spheres per register (one in each half), 10 instructions per pair = 5 per test:
     // 2 x 3 v_pk_fma_f16 for the two projections, 2 v_pk_fma_f16 for p1^2 + p2^2 - rho^2, then the two sign bits
     // (bits 31 and 15) are rotated to their place in the word's mask and merged (v_alignbit_b32, v_and_or_b32).
@@ -477,36 +481,42 @@ struct Intersector {
                     list_base = w * 32;
                 }
                 uint32_t m = always[w];
-                // four pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one between
-                // them on gfx950), with the next four records already requested
-                auto q0 = loadq(w * 16 + 0), q1 = loadq(w * 16 + 1), q2 = loadq(w * 16 + 2), q3 = loadq(w * 16 + 3);
+                // kPairGroup pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one
+                // between them on gfx950), with the next group's records already requested
+                typedef decltype(loadq(0)) Rec;
+                Rec q[kPairGroup];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nx = w * 16 + (g < 3 ? 4 * (g + 1) : 4 * g);      // last group: re-reads itself, never beyond the word
-                    const auto n0 = loadq(nx + 0), n1 = loadq(nx + 1), n2 = loadq(nx + 2), n3 = loadq(nx + 3);
-                    RTK_SCHED_BARRIER();      // keep these four requests ahead of the arithmetic on the previous four
-                    H2 x0 = h2_fma(h2_from_bits(q0.x), f.a1, f.n1), x1 = h2_fma(h2_from_bits(q1.x), f.a1, f.n1);
-                    H2 x2 = h2_fma(h2_from_bits(q2.x), f.a1, f.n1), x3 = h2_fma(h2_from_bits(q3.x), f.a1, f.n1);
-                    H2 y0 = h2_fma(h2_from_bits(q0.x), f.a2, f.n2), y1 = h2_fma(h2_from_bits(q1.x), f.a2, f.n2);
-                    H2 y2 = h2_fma(h2_from_bits(q2.x), f.a2, f.n2), y3 = h2_fma(h2_from_bits(q3.x), f.a2, f.n2);
-                    x0 = h2_fma(h2_from_bits(q0.y), f.b1, x0); x1 = h2_fma(h2_from_bits(q1.y), f.b1, x1);
-                    x2 = h2_fma(h2_from_bits(q2.y), f.b1, x2); x3 = h2_fma(h2_from_bits(q3.y), f.b1, x3);
-                    y0 = h2_fma(h2_from_bits(q0.y), f.b2, y0); y1 = h2_fma(h2_from_bits(q1.y), f.b2, y1);
-                    y2 = h2_fma(h2_from_bits(q2.y), f.b2, y2); y3 = h2_fma(h2_from_bits(q3.y), f.b2, y3);
-                    x0 = h2_fma(h2_from_bits(q0.z), f.c1, x0); x1 = h2_fma(h2_from_bits(q1.z), f.c1, x1);
-                    x2 = h2_fma(h2_from_bits(q2.z), f.c1, x2); x3 = h2_fma(h2_from_bits(q3.z), f.c1, x3);
-                    y0 = h2_fma(h2_from_bits(q0.z), f.c2, y0); y1 = h2_fma(h2_from_bits(q1.z), f.c2, y1);
-                    y2 = h2_fma(h2_from_bits(q2.z), f.c2, y2); y3 = h2_fma(h2_from_bits(q3.z), f.c2, y3);
-                    x0 = h2_fma(x0, x0, h2_from_bits(q0.w)); x1 = h2_fma(x1, x1, h2_from_bits(q1.w));
-                    x2 = h2_fma(x2, x2, h2_from_bits(q2.w)); x3 = h2_fma(x3, x3, h2_from_bits(q3.w));
-                    const uint32_t d0 = h2_bits(h2_fma(y0, y0, x0)), d1 = h2_bits(h2_fma(y1, y1, x1));
-                    const uint32_t d2 = h2_bits(h2_fma(y2, y2, x2)), d3 = h2_bits(h2_fma(y3, y3, x3));
-                    const int k = 4 * g;
-                    m |= (d0 >> k) & (0x80008000u >> k);
-                    m |= (d1 >> (k + 1)) & (0x80008000u >> (k + 1));
-                    m |= (d2 >> (k + 2)) & (0x80008000u >> (k + 2));
-                    m |= (d3 >> (k + 3)) & (0x80008000u >> (k + 3));
-                    q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+                for (int j = 0; j < kPairGroup; ++j) q[j] = loadq(w * 16 + j);
+#pragma unroll
+                for (int g = 0; g < 16 / kPairGroup; ++g) {
+                    // last group: re-reads itself, never beyond the word
+                    const int nx = w * 16 + kPairGroup * (g + 1 < 16 / kPairGroup ? g + 1 : g);
+                    Rec nq[kPairGroup];
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
+                    RTK_SCHED_BARRIER();      // keep these requests ahead of the arithmetic on the previous group
+                    H2 x[kPairGroup], y[kPairGroup];
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].y), f.b1, x[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].y), f.b2, y[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].z), f.c1, x[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].z), f.c2, y[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(x[j], x[j], h2_from_bits(q[j].w));
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) {
+                        const int k = kPairGroup * g + j;
+                        m |= (h2_bits(h2_fma(y[j], y[j], x[j])) >> k) & (0x80008000u >> k);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) q[j] = nq[j];
                 }
                 RTK_STAT(lane, filter_words);
                 emit(w * 32, to_cand(m, 0xFFFFFFFFu));
