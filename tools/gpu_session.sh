@@ -9,6 +9,7 @@
 #   rates    issue rates of candidate filter instructions                  -> gpurun_out/<tag>_valu_rates.txt
 #   ab       interleaved A/B of the kernel variants at 100 spp             -> gpurun_out/<tag>_ab.txt
 #   profile  rocprofv3 kernel trace + PMC passes (tools/profile.sh)        -> gpurun_out/prof_<tag>/
+#   variant  GPU parity tests + bench of one experiment build (3rd argument)   -> gpurun_out/<tag>_tests_<name>.log, _bench_<name>.json
 #   config4  list walk vs uniform grid on the 10k-sphere scene             -> gpurun_out/<tag>_config4_*.json
 #   overlap  one vs two frames in flight, full frame and an eighth of it   -> gpurun_out/<tag>_overlap*.json
 set -u
@@ -40,6 +41,10 @@ case "$STAGE" in
     step 300 gpurun_out/${TAG}_config4_staged.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_staged.so python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
     step 300 gpurun_out/${TAG}_config4_grid.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline --accel grid
     step 300 gpurun_out/${TAG}_stock_grid.json python bench.py --accel grid --no-cpu-baseline ;;
+  variant)   # gpu_session.sh variant <tag> <name>: the GPU parity tests against an experiment build before it is timed
+    NAME=${3:?variant name (f16, smem, exactg, staged)}
+    step 900 gpurun_out/${TAG}_tests_${NAME}.log env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_${NAME}.so python -u -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py -m gpu -x -q --timeout 120 --timeout-method thread
+    step 300 gpurun_out/${TAG}_bench_${NAME}.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_${NAME}.so python bench.py --no-cpu-baseline ;;
   overlap)
     step 300 gpurun_out/${TAG}_overlap1.json python bench.py --no-cpu-baseline
     step 300 gpurun_out/${TAG}_overlap2.json python bench.py --no-cpu-baseline --frames-in-flight 2
