@@ -1,7 +1,7 @@
 """Randomised soak of the filter's conservativeness and the intersector's parity on the CPU build of the device
 code (tests/cpu_emul): random scenes (sizes, scales, offsets, radius spreads), random + tangent + surface rays,
 +-3 ulp perturbation of the hardware approximations.  Prints a summary line per scene; exits non-zero on any miss.
-usage: python tools/soak_filter.py [n_scenes] [seed]"""
+usage: python tools/soak_filter.py [n_scenes] [seed] [build]     build: 1 (default, shipped f32 filter) or f2 (packed-f16 filter)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,9 @@ from test_emul_intersect import tangent_rays
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+build = sys.argv[3] if len(sys.argv) > 3 else "1"
+build = "f2" if build == "f2" else 1
+noise = 2 if build == "f2" else 3        # binary16 ulps for f2 (4x the rounding its margins assume), f32 ulps otherwise
 pairs = rays_total = 0
 t0 = time.time()
 for it in range(n_scenes):
@@ -40,10 +43,10 @@ for it in range(n_scenes):
     rays[: m // 3, 0:3] = np.stack([s["cx"][k], s["cy"][k], s["cz"][k]], 1) + nrm * np.abs(s["radius"][k])[:, None]
     finite = np.isfinite(s["radius"])
     allr = np.concatenate([rays] + [tangent_rays(rng, s, 1500, lo * scale, hi * scale, eps) for lo, hi, eps in ((0.01, 10, 1e-6), (10, 1e3, 1e-4), (1e3, 1e6, 1e-2))])
-    e = Emul(s); o = po.Oracle(); o.set_scene(s)
+    e = Emul(s, lanes=build); o = po.Oracle(); o.set_scene(s)
     ho, io, to = o.intersect(allr)
     dp = o.disc_pass(allr)
-    hit, idx, t, flags = e.intersect(allr, want_flags=True, ulp_noise=3)
+    hit, idx, t, flags = e.intersect(allr, want_flags=True, ulp_noise=noise)
     miss = int(((dp == 1) & (flags == 0)).sum())
     nan = np.isnan(to)
     ok = miss == 0 and np.array_equal(hit, ho) and np.array_equal(idx, io) and np.array_equal(np.isnan(t), nan) and np.array_equal(t.view(np.uint32)[~nan], to.view(np.uint32)[~nan])
