@@ -288,3 +288,29 @@ def test_sharded_u8_gather_matches_f32_path(stock_scene_golden):
     assert np.array_equal(img.cpu().numpy(), deinterleave(g.cpu().numpy(), W, H, world))
     ctx.set_stream(0)
     ctx.close()
+
+
+def test_drop_in_executable_writes_the_reference_file(gpu_ctx, tmp_path):
+    """raytracinginoneweekend_amd/host/rtiow_amd is the reference's main (main.cpp:20-81) on top of librtk: same argv,
+    same image_binary.ppm.  Its payload must be exactly what rtk_render_u8 gives for the same scene, camera and seed,
+    in a process of its own (no torch, its own HIP runtime)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "host", "rtiow_amd")
+    assert os.path.exists(exe), "build it with python -m raytracinginoneweekend_amd.build"
+    W, H, spp, depth = 64, 42, 16, 50
+    r = subprocess.run([exe, str(W), str(H), str(spp), str(depth)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Image Generation took" in r.stderr and "Done." in r.stderr          # the reference's own progress / timing lines
+    data = (tmp_path / "image_binary.ppm").read_bytes()
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    assert data.startswith(header) and len(data) == len(header) + W * H * 3
+    got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+    want, _ = gpu_ctx.render_u8(rt.stock_camera(float(np.float32(W) / np.float32(H))), W, H, spp, depth, seed=0)
+    assert np.array_equal(got, want)
+    # progressive passes (rtk_params::sample_offset, sums added on the host) reach the same picture
+    r = subprocess.run([exe, str(W), str(H), str(spp), str(depth), "0", "0", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    data2 = (tmp_path / "image_binary.ppm").read_bytes()
+    got2 = np.frombuffer(data2[len(header):], np.uint8).reshape(H, W, 3)
+    assert np.abs(got2.astype(int) - want.astype(int)).max() <= 1               # four fp32 partial sums instead of one: last-bit rounding only
