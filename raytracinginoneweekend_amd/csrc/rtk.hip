@@ -28,7 +28,8 @@ using namespace rtk;
 #ifndef RTK_EXACT_GLOBAL
 #define RTK_EXACT_GLOBAL 0
 #endif
-constexpr int kLdsBytesPerSphere = RTK_EXACT_GLOBAL ? 16 : 32;
+// (RTK_SMEM builds read the filter operands by scalar loads from global memory: no LDS copy of them either.)
+constexpr int kLdsBytesPerSphere = (RTK_SMEM ? 0 : 16) + (RTK_EXACT_GLOBAL ? 0 : 16);
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
@@ -36,19 +37,22 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {
-        float4* lf = reinterpret_cast<float4*>(p);
-#if RTK_EXACT_GLOBAL
+        float4* cursor = reinterpret_cast<float4*>(p);
+#if RTK_SMEM
+        it.filt = sc.filt;
+#else
+        float4* lf = cursor;
+        cursor += sc.npad;
         for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) lf[i] = sc.filt[i];
+        it.filt = lf;
+#endif
+#if RTK_EXACT_GLOBAL
         it.exact = sc.exact;
 #else
-        float4* le = lf + sc.npad;
-        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) {
-            lf[i] = sc.filt[i];
-            le[i] = sc.exact[i];
-        }
+        float4* le = cursor;
+        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) le[i] = sc.exact[i];
         it.exact = le;
 #endif
-        it.filt = lf;
         p += static_cast<size_t>(sc.npad) * kLdsBytesPerSphere;
     } else {
         it.filt = sc.filt;

@@ -16,6 +16,7 @@ VARIANTS = {
     "smem": ["-DRTK_SMEM=1"],                      # filter operands by scalar loads from the GLOBAL copy (SGPR operands)
     "f16": ["-DRTK_FILTER_FORM=2"],                # packed-f16 projection filter: 3 v_pk_fma_f16 + v_dot2_f32_f16 + v_alignbit per test (5 instead of 9)
     "f16smem": ["-DRTK_FILTER_FORM=2", "-DRTK_SMEM=1"],   # both: pair records by s_load_dwordx16 (8 spheres per load), v_pk_fma_f16 with SGPR sources, no LDS in the loop
+    "f16smem_exactg": ["-DRTK_FILTER_FORM=2", "-DRTK_SMEM=1", "-DRTK_EXACT_GLOBAL=1"],   # ... and no scene data in LDS at all (8 KiB of candidate lists per workgroup)
     "exactg": ["-DRTK_EXACT_GLOBAL=1"],            # exact-stage operands from global memory: 16 instead of 24 KiB LDS per workgroup (7 waves/SIMD)
     "staged": ["-DRTK_STAGED_LARGE=1"],            # scenes > 1024 spheres: stream the list through wave-private LDS chunks (only differs for such scenes)
 }
