@@ -62,3 +62,44 @@ def test_shard_gather_deinterleave(tmp_path, world, W, H):
         assert np.array_equal(img[..., 2], owner)          # every pixel came from the rank that owns its tile
         img8 = np.load(tmp_path / f"img8_{r}.npy")
         assert img8.dtype == np.uint8 and np.array_equal(img8[..., 0], (p % 251).astype(np.uint8))
+
+
+def _render_worker(rank, world, W, H, port, out_dir):
+    """Each rank renders ITS tiles with the CPU build of the render kernel (the same device source the GPU runs),
+    then the ranks exchange them exactly as bench.py does on RCCL."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raytracinginoneweekend_amd as rt
+    from raytracinginoneweekend_amd import distributed as rd
+    from emul import Emul
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    e = Emul(rt.stock_scene())
+    cam = rt.stock_camera(W / H)
+    tprp = rd.tiles_per_rank_padded(W, H, world)
+    tiles, st = e.render_tiles(cam, rt.make_params(W, H, 3, 12, 5, 0.001, rank, world), threads=2)
+    local = torch.zeros((tprp, 64, 3), dtype=torch.float32)
+    local[: len(tiles)] = torch.from_numpy(tiles)
+    img = deinterleave(rd.gather_tiles(local).numpy(), W, H, world)
+    rays = torch.tensor([st["rays"]], dtype=torch.int64)
+    dist.all_reduce(rays)
+    np.save(os.path.join(out_dir, f"render{rank}.npy"), img)
+    np.save(os.path.join(out_dir, f"rays{rank}.npy"), rays.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_render_equals_single_rank(tmp_path):
+    """World size 2 end to end on the CPU: the gathered, de-interleaved image has exactly the bits — and the ranks
+    together trace exactly the rays — of a single-rank render (global-pixel RNG keys, integer accumulation)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raytracinginoneweekend_amd as rt
+    from emul import Emul
+    world, W, H = 2, 37, 23
+    port = 29000 + (os.getpid() * 11 + 977) % 2000
+    mp.spawn(_render_worker, args=(world, W, H, port, str(tmp_path)), nprocs=world, join=True)
+    ref, st = Emul(rt.stock_scene()).render(rt.stock_camera(W / H), W, H, 3, 12, seed=5, threads=2)
+    for r in range(world):
+        img = np.load(tmp_path / f"render{r}.npy")
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        assert int(np.load(tmp_path / f"rays{r}.npy")[0]) == st["rays"]
