@@ -197,120 +197,3 @@ def test_render_argument_errors(gpu_ctx):
         gpu_ctx.render(cam, 16, 16, 1, 1, tile_w=8, tile_h=4)
     with pytest.raises(rt.RtkError, match="spp"):
         gpu_ctx.render(cam, 16, 16, 0, 1)
-
-
-def test_context_reuse_and_material_none(stock_scene_golden):
-    """One context, several scenes one after another (HittableList::clear()/add() on the host side means a new
-    rtk_set_scene), and Material::Type::None absorbing every path it meets."""
-    ctx = rt.Context(0)
-    cam = rt.stock_camera(1.5)
-    small = {k: v[:40].copy() for k, v in stock_scene_golden.items()}
-    ctx.set_scene(small)
-    a, _ = ctx.render(cam, 48, 32, 8, 50, seed=2)
-    ctx.set_scene(stock_scene_golden)
-    b, sb = ctx.render(cam, 48, 32, 8, 50, seed=2)
-    ctx.set_scene(small)
-    a2, _ = ctx.render(cam, 48, 32, 8, 50, seed=2)
-    assert np.array_equal(bits(a), bits(a2)) and not np.array_equal(a, b)
-    none = {k: v.copy() for k, v in stock_scene_golden.items()}
-    none["mat_type"][:] = 0
-    ctx.set_scene(none)
-    img, st = ctx.render(cam, 48, 32, 8, 50, seed=2)
-    assert st["rays"] == st["samples"] and not img[-1].any() and img[0].min() > 0
-    ctx.close()
-
-
-def test_progressive_batches_cover_the_same_samples(gpu_ctx):
-    """rtk_params::sample_offset (progressive rendering): two passes trace exactly the samples of one frame."""
-    cam = rt.stock_camera(1.5)
-    full, sf = gpu_ctx.render(cam, 60, 40, 24, 50, seed=9, run_len=4)
-    a, sa = gpu_ctx.render(cam, 60, 40, 12, 50, seed=9, run_len=4, sample_offset=0)
-    b, sb = gpu_ctx.render(cam, 60, 40, 12, 50, seed=9, run_len=4, sample_offset=12)
-    assert sa["rays"] + sb["rays"] == sf["rays"] and sa["samples"] + sb["samples"] == sf["samples"]
-    assert np.allclose(a + b, full, rtol=2e-6, atol=1e-6) and not np.array_equal(a, b)
-    with pytest.raises(rt.RtkError, match="sample_offset"):
-        gpu_ctx.render(cam, 16, 16, 4, 1, sample_offset=-1)
-
-
-def test_sharded_renderer_single_rank_matches_rtk_render(stock_scene_golden):
-    """bench.py's path (ShardedRenderer on its own torch stream: tiles -> gather -> de-interleave) at world size 1."""
-    import torch
-    from raytracinginoneweekend_amd.distributed import ShardedRenderer
-    ctx = rt.Context(0)
-    ctx.set_scene(stock_scene_golden)
-    W, H = 100, 60
-    cam = rt.stock_camera(W / H)
-    ref, st = ctx.render(cam, W, H, 16, 50, seed=4)
-    sr = ShardedRenderer(ctx, W, H, 0, 1, torch.device("cuda", 0))
-    for _ in range(2):                                       # twice: the accumulators must come back zeroed
-        sr.render(cam, 16, 50, seed=4)
-        sr.synchronize()
-        assert np.array_equal(bits(sr.image.cpu().numpy()), bits(ref))
-    ctx.set_stream(0)
-    ctx.close()
-
-
-def test_render_u8_is_write_color_binary_of_render(gpu_ctx):
-    """rtk_render_u8: the device-side gamma/quantise gives exactly the bytes the reference's
-    write_color_binary (Color.hpp:28-48, restated by the oracle) produces from rtk_render's sums."""
-    cam = rt.stock_camera(1.5)
-    sums, st = gpu_ctx.render(cam, 90, 60, 20, 50, seed=12)
-    u8, st8 = gpu_ctx.render_u8(cam, 90, 60, 20, 50, seed=12)
-    assert st["rays"] == st8["rays"]
-    assert np.array_equal(u8, po.quantise(sums, 20))
-    with pytest.raises(rt.RtkError, match="null"):
-        rt._check(rt.lib().rtk_render_u8(gpu_ctx._h, None, None, None, None), "rtk_render_u8")
-
-
-def test_sharded_u8_gather_matches_f32_path(stock_scene_golden):
-    """ShardedRenderer(output="u8"): tiles quantised before the gather, bytes de-interleaved on the device."""
-    import torch
-    from raytracinginoneweekend_amd.distributed import ShardedRenderer
-    ctx = rt.Context(0)
-    ctx.set_scene(stock_scene_golden)
-    W, H, spp = 100, 60, 16
-    cam = rt.stock_camera(W / H)
-    sr = ShardedRenderer(ctx, W, H, 0, 1, torch.device("cuda", 0))
-    sr.render(cam, spp, 50, seed=4)
-    sr.synchronize()
-    want = po.quantise(sr.image.cpu().numpy(), spp)
-    sr.render(cam, spp, 50, seed=4, output="u8")
-    sr.synchronize()
-    assert np.array_equal(sr.image_u8.cpu().numpy(), want)
-    # the byte de-interleave for several ranks, against the numpy restatement of the index math
-    world = 3
-    tprp = rt.local_tile_count(W, H, 0, world)
-    g = torch.randint(0, 256, (world, tprp, 64, 3), dtype=torch.uint8, device="cuda:0")
-    img = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
-    torch.cuda.synchronize()
-    ctx.deinterleave_u8_device(g.data_ptr(), tprp, rt.make_params(W, H, 1, 1, 0, 0.001, 0, world), img.data_ptr())
-    ctx.synchronize()
-    assert np.array_equal(img.cpu().numpy(), deinterleave(g.cpu().numpy(), W, H, world))
-    ctx.set_stream(0)
-    ctx.close()
-
-
-def test_drop_in_executable_writes_the_reference_file(gpu_ctx, tmp_path):
-    """raytracinginoneweekend_amd/host/rtiow_amd is the reference's main (main.cpp:20-81) on top of librtk: same argv,
-    same image_binary.ppm.  Its payload must be exactly what rtk_render_u8 gives for the same scene, camera and seed,
-    in a process of its own (no torch, its own HIP runtime)."""
-    import os
-    import subprocess
-    exe = os.path.join(os.path.dirname(rt.__file__), "host", "rtiow_amd")
-    assert os.path.exists(exe), "build it with python -m raytracinginoneweekend_amd.build"
-    W, H, spp, depth = 64, 42, 16, 50
-    r = subprocess.run([exe, str(W), str(H), str(spp), str(depth)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "Image Generation took" in r.stderr and "Done." in r.stderr          # the reference's own progress / timing lines
-    data = (tmp_path / "image_binary.ppm").read_bytes()
-    header = b"P6\n%d %d\n255\n" % (W, H)
-    assert data.startswith(header) and len(data) == len(header) + W * H * 3
-    got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
-    want, _ = gpu_ctx.render_u8(rt.stock_camera(float(np.float32(W) / np.float32(H))), W, H, spp, depth, seed=0)
-    assert np.array_equal(got, want)
-    # progressive passes (rtk_params::sample_offset, sums added on the host) reach the same picture
-    r = subprocess.run([exe, str(W), str(H), str(spp), str(depth), "0", "0", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    data2 = (tmp_path / "image_binary.ppm").read_bytes()
-    got2 = np.frombuffer(data2[len(header):], np.uint8).reshape(H, W, 3)
-    assert np.abs(got2.astype(int) - want.astype(int)).max() <= 1               # four fp32 partial sums instead of one: last-bit rounding only
