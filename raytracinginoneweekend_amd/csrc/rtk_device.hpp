@@ -303,6 +303,14 @@ struct Intersector {
     };
 
 #if RTK_FILTER_FORM == 2
+    // `always` is SceneDev::always_mask: device GLOBAL memory, read-only while a kernel runs, indexed by a wave-uniform
+    // word number — read with a scalar load (constant address space) so it costs no vector register.  (Never apply
+    // this cast to an LDS pointer.)
+#ifdef RTK_HOST_EMULATION
+#define RTK_ALWAYS_LOAD(w) (always[w])
+#else
+#define RTK_ALWAYS_LOAD(w) (reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(always))[w])
+#endif
 #ifndef RTK_PAIR_GROUP
 #define RTK_PAIR_GROUP 2
 #endif
@@ -474,13 +482,15 @@ struct Intersector {
         // mask has the first np spheres in bits 31.. and the rest in bits 15.. (for a full word that IS the usual
         // MSB-first order; a partial last word shifts its low half up).
         auto scan_pairs = [&](auto&& loadq, int count) {
-            const int full = count >> 5, rem = count & 31;
+            const int full = count >> 5, rem = count & 31, last_word = (count - 1) >> 5;
+            uint32_t aw = RTK_ALWAYS_LOAD(0);     // the always-mask of word w is requested one word ahead
             for (int w = 0; w < full; ++w) {
                 if (w * 32 - list_base > 65535 - 64) {
                     flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
                     list_base = w * 32;
                 }
-                uint32_t m = always[w];
+                uint32_t m = aw;
+                aw = RTK_ALWAYS_LOAD(w < last_word ? w + 1 : w);
                 // kPairGroup pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one
                 // between them on gfx950), with the next group's records already requested
                 typedef decltype(loadq(0)) Rec;
@@ -530,7 +540,7 @@ struct Intersector {
                     const uint32_t d = filter_pair_f16(f, q.x, q.y, q.z, q.w);
                     m |= __builtin_amdgcn_alignbit(d, d, k) & (0x80008000u >> k);
                 }
-                m = ((m & 0xFFFF0000u) | ((m & 0xFFFFu) << (16 - np))) | always[full];
+                m = ((m & 0xFFFF0000u) | ((m & 0xFFFFu) << (16 - np))) | aw;
                 emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
