@@ -57,7 +57,7 @@ def test_f16_random_rays_bulk(stock_scene_golden):
     check(stock_scene_golden, rays, noises=(2,))
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 33, 100, 1025])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 1025])
 def test_f16_scene_sizes(n):
     rng = np.random.default_rng(n)
     s = _odd_scene(rng, n)
