@@ -92,7 +92,8 @@ typedef struct rtk_params {
 typedef struct rtk_stats {
     uint64_t rays;
     uint64_t samples;
-    uint64_t sphere_tests;     /* rays x scene size: the filter tests every sphere for every segment */
+    uint64_t sphere_tests;     /* list walk: rays x scene size (the filter tests every sphere for every segment);
+                                * uniform grid: the exact tests of the cells the rays crossed */
     uint64_t exact_tests;      /* candidates re-tested with the reference's exact arithmetic */
     uint64_t lane_slots;       /* 64 x wavefront passes through the intersection loop */
     float kernel_ms;           /* HIP-event time of the render kernel alone, summed over `frames_timed` frames */
@@ -124,7 +125,7 @@ int rtk_context_set_stream(rtk_context* ctx, void* hip_stream);
  *   RTK_ACCEL_GRID: a uniform grid over the spheres, built by the library at rtk_set_scene / at this call; a ray
  *     tests only the spheres registered in the cells it crosses.  Results (hit, index, t, images, ray counts) are
  *     bit-identical to the list walk; rays the grid's margins were not sized for (non-finite, origins farther than
- *     the scene's diagonal from its centre) take the list walk inside the same kernel.  Meant for lists far beyond
+ *     3/4 of the scene's diagonal from its centre) take the list walk inside the same kernel.  Meant for lists far beyond
  *     the 1024 spheres that fit in LDS (BASELINE.json config 4).
  * A scene that cannot be put in a grid (a non-finite sphere: the reference's result then depends on the LIST order)
  * is rendered with the list walk; rtk_accel_in_use tells which one the next call will take and rtk_last_error()
