@@ -246,25 +246,43 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
         for (int k = 0; k < 3; ++k) { glo[k] = std::min(glo[k], c[k] - rbox[i]); ghi[k] = std::max(ghi[k], c[k] + rbox[i]); }
     }
     int nc[3];
-    for (;;) {
-        double cells = 1.0;
-        for (int k = 0; k < 3; ++k) {
-            nc[k] = static_cast<int>(std::min(1024.0, std::max(1.0, std::floor((ghi[k] - glo[k]) / h0))));
-            cells *= nc[k];
-        }
-        if (cells <= 8.0 * in.size() + 4096.0) break;
-        h0 *= 1.25;
-    }
-    // float parameters exactly as the device will use them; cell sizes rounded up so that lo + n h covers the box
     float lof[3], hf[3], hif[3], ihf[3];
-    for (int k = 0; k < 3; ++k) {
-        lof[k] = std::nextafter(static_cast<float>(glo[k]), -std::numeric_limits<float>::infinity());
-        double h = (ghi[k] - static_cast<double>(lof[k])) / nc[k];
-        if (!(h > 0.0)) h = 1.0;
-        hf[k] = std::nextafter(static_cast<float>(h * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
-        hif[k] = std::nextafter(static_cast<float>(static_cast<double>(lof[k]) + static_cast<double>(nc[k]) * hf[k]), std::numeric_limits<float>::infinity());
-        ihf[k] = static_cast<float>(1.0 / static_cast<double>(hf[k]));
-        if (!std::isfinite(lof[k]) || !std::isfinite(hf[k]) || !std::isfinite(hif[k]) || !std::isfinite(ihf[k]) || !(ihf[k] > 0.0f)) { g.why = "scene extent is not representable"; return; }
+    // Resolution: cells of about twice the median inflated radius, coarsened until the grid has at most 8 cells per
+    // sphere and the spheres' registrations at most ~64 per sphere (bimodal radii would otherwise register the
+    // large spheres in thousands of cells each).
+    for (int attempt = 0;; ++attempt) {
+        for (;;) {
+            double cells = 1.0;
+            for (int k = 0; k < 3; ++k) {
+                nc[k] = static_cast<int>(std::min(1024.0, std::max(1.0, std::floor((ghi[k] - glo[k]) / h0))));
+                cells *= nc[k];
+            }
+            if (cells <= 8.0 * in.size() + 4096.0) break;
+            h0 *= 1.25;
+        }
+        // float parameters exactly as the device will use them; cell sizes rounded up so that lo + n h covers the box
+        for (int k = 0; k < 3; ++k) {
+            lof[k] = std::nextafter(static_cast<float>(glo[k]), -std::numeric_limits<float>::infinity());
+            double h = (ghi[k] - static_cast<double>(lof[k])) / nc[k];
+            if (!(h > 0.0)) h = 1.0;
+            hf[k] = std::nextafter(static_cast<float>(h * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
+            hif[k] = std::nextafter(static_cast<float>(static_cast<double>(lof[k]) + static_cast<double>(nc[k]) * hf[k]), std::numeric_limits<float>::infinity());
+            ihf[k] = static_cast<float>(1.0 / static_cast<double>(hf[k]));
+            if (!std::isfinite(lof[k]) || !std::isfinite(hf[k]) || !std::isfinite(hif[k]) || !std::isfinite(ihf[k]) || !(ihf[k] > 0.0f)) { g.why = "scene extent is not representable"; return; }
+        }
+        double registrations = 0.0;
+        for (int i : in) {
+            double span = 1.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];
+                const double lo_c = std::max(0.0, std::floor((c - rbox[i] - lof[k]) / hf[k])), hi_c = std::min(nc[k] - 1.0, std::floor((c + rbox[i] - lof[k]) / hf[k]));
+                span *= std::max(1.0, hi_c - lo_c + 1.0);
+            }
+            if (span <= kGridMaxCellsPerSphere) registrations += span;
+        }
+        if (registrations <= 64.0 * in.size() + 1048576.0) break;
+        if (attempt == 16 || (nc[0] == 1 && nc[1] == 1 && nc[2] == 1)) { g.why = "grid too large"; return; }
+        h0 *= 1.5;
     }
     auto range = [&](int i, int k, int& a, int& b) {
         const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];

@@ -170,3 +170,20 @@ def test_grid_in_64_lane_waves(stock_scene_golden):
     b, sb = e.render(cam, 37, 23, 6, 50, seed=5, threads=3, accel=1)
     assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
     assert emul.lib(64).emul_simt_error() == 0
+
+
+def test_grid_bimodal_radii_stay_bounded():
+    """Half specks, half large spheres: the median cell size would register every large sphere in hundreds of cells;
+    the builder coarsens the grid instead (registrations stay near 64 per sphere) and results are unchanged."""
+    rng = np.random.default_rng(21)
+    n = 4000
+    s = _odd_scene(rng, n)
+    s["cx"] = rng.uniform(-60, 60, n).astype(np.float32); s["cz"] = rng.uniform(-60, 60, n).astype(np.float32)
+    s["cy"] = rng.uniform(-3, 3, n).astype(np.float32)
+    s["radius"] = np.where(np.arange(n) % 2 == 0, 0.02, 2.5).astype(np.float32)
+    e = Emul(s)
+    g = e.grid_info()
+    assert g["usable"] and g["items"] <= 64 * n + (1 << 20)
+    m = 1500
+    rays = np.concatenate([rng.uniform(-60, 60, (m, 3)) * np.array([1, 0.05, 1]), rng.normal(size=(m, 3))], 1).astype(np.float32)
+    check_grid(s, rays, e=e)
