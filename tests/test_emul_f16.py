@@ -114,3 +114,21 @@ def test_f16_render_is_bit_identical_to_the_f32_filter(stock_scene_golden):
     b, sb = Emul(stock_scene_golden, lanes="f2").render(cam, 60, 40, 6, 50, seed=3, threads=4)
     assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
     assert sb["exact_tests"] < 1.35 * sa["exact_tests"]
+
+
+def test_f16_in_64_lane_waves(stock_scene_golden):
+    """The pair loop's per-wave pieces (candidate lists with the 64-lane stride, early flushes when a lane's list
+    fills, the uniform always-mask) under 64 fibers per wave."""
+    import emul
+    z = load_golden("rays_stock.npz")
+    e = Emul(stock_scene_golden, lanes="f2x64")
+    for batch, count in (("secondary", 1000), ("grazing", 700), ("degenerate", 93)):
+        hit, idx, t = e.intersect(z[batch + "_rays"][:count])
+        nan = np.isnan(z[batch + "_t"][:count])
+        assert np.array_equal(hit, z[batch + "_hit"][:count]) and np.array_equal(idx, z[batch + "_index"][:count])
+        assert np.array_equal(bits(t)[~nan], bits(z[batch + "_t"][:count])[~nan])
+    cam = rt.stock_camera(37 / 23)
+    a, sa = Emul(stock_scene_golden).render(cam, 37, 23, 6, 50, seed=5, threads=2)
+    b, sb = e.render(cam, 37, 23, 6, 50, seed=5, threads=3)
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+    assert emul.lib("f2x64").emul_simt_error() == 0
