@@ -243,7 +243,7 @@ constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 
 // reference's rounding could still accept for ray origins inside the ball (centre, r_allow); the few spheres that
 // are not gridable (non-finite, outliers such as the 1000-unit ground sphere) are tested for every ray.
 struct GridDev {
-    const uint32_t* cell_start;   // [nx*ny*nz + 1]
+    const uint32_t* cell_start;   // [zones][nx*ny*nz + 1]: one registration per zone of ray origins
     const uint32_t* items;        // sphere indices, ascending within a cell
     const uint32_t* always;       // [n_always] ascending: spheres outside the grid
     int32_t n_always;
@@ -252,6 +252,9 @@ struct GridDev {
     float hix, hiy, hiz;
     float hx, hy, hz;             // cell size
     float ihx, ihy, ihz;          // 1 / cell size
+    int32_t znx, zny, znz;        // origin zones over the grid box (outer zones extend outwards)
+    float izx, izy, izz;          // zones per unit length
+    int32_t zone_stride;          // nx*ny*nz + 1
     float cx, cy, cz, r_allow2;   // ray origins inside this ball may use the grid; others take the brute-force path
     float slack;                  // distance by which traversal decisions are widened (float error of the walk)
 };
@@ -645,6 +648,9 @@ struct Intersector {
                     const float f = floorf((p - lo) * ih);
                     return !(f >= 0.0f) ? 0 : (f > static_cast<float>(n - 1) ? n - 1 : static_cast<int>(f));   // NaN and negatives -> 0
                 };
+                // the registration made for origins like this one
+                const uint32_t* cs = G.cell_start + static_cast<size_t>((cell_of(r.o.z, G.loz, G.izz, G.znz) * G.zny + cell_of(r.o.y, G.loy, G.izy, G.zny)) * G.znx +
+                                                                        cell_of(r.o.x, G.lox, G.izx, G.znx)) * static_cast<size_t>(G.zone_stride);
                 int ix = cell_of(fmaf(t0, r.d.x, r.o.x), G.lox, G.ihx, G.nx);
                 int iy = cell_of(fmaf(t0, r.d.y, r.o.y), G.loy, G.ihy, G.ny);
                 int iz = cell_of(fmaf(t0, r.d.z, r.o.z), G.loz, G.ihz, G.nz);
@@ -652,7 +658,7 @@ struct Intersector {
                 // every step moves one cell forward along one axis, so the walk ends after at most nx + ny + nz steps
                 for (int steps = G.nx + G.ny + G.nz; steps > 0; --steps) {
                     const int cell = (iz * G.ny + iy) * G.nx + ix;
-                    const uint32_t b = G.cell_start[cell], e = G.cell_start[cell + 1];
+                    const uint32_t b = cs[cell], e = cs[cell + 1];
                     for (uint32_t q = b; q < e; ++q) test(static_cast<int>(G.items[q]));
                     // parameter at which the ray leaves this cell, per axis (recomputed from the cell index: no drift)
                     const float ex = mx ? (fmaf(static_cast<float>(ix + (sx > 0 ? 1 : 0)), G.hx, G.lox) - r.o.x) * ivx : inf;

@@ -179,11 +179,12 @@ struct GridHost {
 constexpr int kGridMaxAlways = 64;          // spheres tested for every ray; more than this: the grid is refused
 constexpr int kGridMaxCellsPerSphere = 4096;
 
-// Registers every filterable sphere in the cells its inflated box overlaps.
+// Registers every gridable sphere in the cells its inflated box overlaps, once per origin zone.
 // Inflation: the reference accepts a sphere (and returns a root whose point lies) up to sqrt(r^2 + E) from the centre,
-// E = 32u(|oc|^2 + r^2), u = 2^-24; |oc| <= r_allow + D/2 for origins in the ball (centre, r_allow = 0.75 D),
-// D the diagonal of the gridable spheres' bounding box.  On top of that, `slack` = 2^-14 D covers the float error of the
-// device's cell walk (positions are accurate to ~2^-22 D).
+// E = 32u(|oc|^2 + r^2), u = 2^-24, |oc| the distance from the ray's ORIGIN to the centre: bounded per
+// zone of origins; origins are admitted within the ball (centre, r_allow = 0.75 D), D the diagonal of the gridable
+// spheres' bounding box.  On top of that, `slack` = 2^-14 D covers the float error of the device's cell walk
+// (positions are accurate to ~2^-22 D).
 inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g) {
     g = GridHost();
     const int n = s->n;
@@ -228,28 +229,59 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
     const double D = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
     const double centre[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
     const double r_allow = 0.75 * D, oc_max = r_allow + 0.5 * D + r_max;
-    const double u = std::ldexp(1.0, -24), E = 32.0 * u * (oc_max * oc_max + r_max * r_max), slack = std::ldexp(D, -14);
-    std::vector<double> rbox(n, 0.0);
-    std::vector<double> sorted;
-    for (int i : in) {
+    const double u = std::ldexp(1.0, -24), slack = std::ldexp(D, -14);
+    auto inflated = [&](int i, double oc) {          // half-size of sphere i's box for ray origins at most `oc` from its centre
         const double r = std::fabs(static_cast<double>(s->radius[i]));
-        rbox[i] = (std::sqrt(r * r + E) + 2.0 * slack) * (1.0 + 1e-6);
-        sorted.push_back(rbox[i]);
-    }
-    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-    double h0 = 2.0 * sorted[sorted.size() / 2];
-    // the grid box holds every inflated sphere box
+        return (std::sqrt(r * r + 32.0 * u * (oc * oc + r * r)) + 2.0 * slack) * (1.0 + 1e-6);
+    };
+    // the grid box holds every sphere box at its largest inflation (the farthest admissible origin)
     double glo[3], ghi[3];
     for (int k = 0; k < 3; ++k) { glo[k] = 1e300; ghi[k] = -1e300; }
+    std::vector<double> near_box;
     for (int i : in) {
-        const double c[3] = {s->cx[i], s->cy[i], s->cz[i]};
-        for (int k = 0; k < 3; ++k) { glo[k] = std::min(glo[k], c[k] - rbox[i]); ghi[k] = std::max(ghi[k], c[k] + rbox[i]); }
+        const double c[3] = {s->cx[i], s->cy[i], s->cz[i]}, rb = inflated(i, oc_max);
+        for (int k = 0; k < 3; ++k) { glo[k] = std::min(glo[k], c[k] - rb); ghi[k] = std::max(ghi[k], c[k] + rb); }
+        near_box.push_back(inflated(i, D / 6.0));
     }
+    std::nth_element(near_box.begin(), near_box.begin() + near_box.size() / 2, near_box.end());
+    double h0 = 2.0 * near_box[near_box.size() / 2];       // cells of about twice the median box seen from nearby
+    // Origin zones: the inflation a sphere needs grows with the distance of the ray's ORIGIN (the reference's rounding
+    // noise is ~|o - C|^2), so the space of origins is cut into zn[0] x zn[1] x zn[2] zones and every zone gets its own
+    // registration of the spheres, each inflated for the farthest origin of that zone only.  A ray reads the cells of its
+    // origin's zone: nearby spheres have tight boxes, only far ones are fat.
+    int zn[3];
+    for (int k = 0; k < 3; ++k) zn[k] = static_cast<int>(std::min(6.0, std::max(1.0, std::ceil((hi[k] - lo[k]) / (D / 5.0)))));
     int nc[3];
-    float lof[3], hf[3], hif[3], ihf[3];
-    // Resolution: cells of about twice the median inflated radius, coarsened until the grid has at most 8 cells per
-    // sphere and the spheres' registrations at most ~64 per sphere (bimodal radii would otherwise register the
-    // large spheres in thousands of cells each).
+    float lof[3], hf[3], hif[3], ihf[3], izs[3];
+    std::vector<int> gridded;
+    std::vector<char> is_always(n, 0);
+    for (uint32_t a : g.always) is_always[a] = 1;
+    size_t n_cells = 0, n_zones = 0;
+    // zone (zx, zy, zz): the box of origins it serves (outer zones reach to the admissible ball's box; a small overlap
+    // covers the float rounding of the device's zone index)
+    auto zone_box = [&](const int zi[3], double zl[3], double zh[3]) {
+        for (int k = 0; k < 3; ++k) {
+            const double zs = (static_cast<double>(hif[k]) - lof[k]) / zn[k], m = 1e-3 * zs;
+            zl[k] = zi[k] == 0 ? centre[k] - r_allow : std::max(centre[k] - r_allow, lof[k] + zi[k] * zs - m);
+            zh[k] = zi[k] == zn[k] - 1 ? centre[k] + r_allow : std::min(centre[k] + r_allow, lof[k] + (zi[k] + 1) * zs + m);
+            if (zh[k] < zl[k]) zh[k] = zl[k];
+        }
+    };
+    auto box_for_zone = [&](int i, const double zl[3], const double zh[3]) {
+        const double c[3] = {s->cx[i], s->cy[i], s->cz[i]};
+        double far2 = 0.0;
+        for (int k = 0; k < 3; ++k) { const double f = std::max(std::fabs(c[k] - zl[k]), std::fabs(c[k] - zh[k])); far2 += f * f; }
+        return inflated(i, std::sqrt(far2));
+    };
+    auto range = [&](int i, double rb, int k, int& a, int& b) {
+        const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];
+        a = static_cast<int>(std::floor((c - rb - lof[k]) / hf[k]));
+        b = static_cast<int>(std::floor((c + rb - lof[k]) / hf[k]));
+        a = std::max(0, std::min(nc[k] - 1, a));
+        b = std::max(0, std::min(nc[k] - 1, b));
+    };
+    // Resolution and zone count: coarsened until the grid has at most 8 cells per sphere and all zones together hold
+    // at most ~32M registrations.
     for (int attempt = 0;; ++attempt) {
         for (;;) {
             double cells = 1.0;
@@ -268,55 +300,73 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
             hf[k] = std::nextafter(static_cast<float>(h * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
             hif[k] = std::nextafter(static_cast<float>(static_cast<double>(lof[k]) + static_cast<double>(nc[k]) * hf[k]), std::numeric_limits<float>::infinity());
             ihf[k] = static_cast<float>(1.0 / static_cast<double>(hf[k]));
-            if (!std::isfinite(lof[k]) || !std::isfinite(hf[k]) || !std::isfinite(hif[k]) || !std::isfinite(ihf[k]) || !(ihf[k] > 0.0f)) { g.why = "scene extent is not representable"; return; }
+            izs[k] = static_cast<float>(zn[k] / (static_cast<double>(hif[k]) - lof[k]));
+            if (!std::isfinite(lof[k]) || !std::isfinite(hf[k]) || !std::isfinite(hif[k]) || !std::isfinite(ihf[k]) || !(ihf[k] > 0.0f) || !std::isfinite(izs[k])) { g.why = "scene extent is not representable"; return; }
         }
+        n_cells = static_cast<size_t>(nc[0]) * nc[1] * nc[2];
+        n_zones = static_cast<size_t>(zn[0]) * zn[1] * zn[2];
+        // spheres that span too many cells in ANY zone are tested for every ray instead
+        std::vector<char> fat(n, 0);
         double registrations = 0.0;
-        for (int i : in) {
-            double span = 1.0;
-            for (int k = 0; k < 3; ++k) {
-                const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];
-                const double lo_c = std::max(0.0, std::floor((c - rbox[i] - lof[k]) / hf[k])), hi_c = std::min(nc[k] - 1.0, std::floor((c + rbox[i] - lof[k]) / hf[k]));
-                span *= std::max(1.0, hi_c - lo_c + 1.0);
+        for (int z = 0; z < static_cast<int>(n_zones); ++z) {
+            const int zi[3] = {z % zn[0], (z / zn[0]) % zn[1], z / (zn[0] * zn[1])};
+            double zl[3], zh[3];
+            zone_box(zi, zl, zh);
+            for (int i : in) {
+                const double rb = box_for_zone(i, zl, zh);
+                double span = 1.0;
+                for (int k = 0; k < 3; ++k) { int a, b; range(i, rb, k, a, b); span *= (b - a + 1); }
+                if (span > kGridMaxCellsPerSphere) fat[i] = 1; else registrations += span;
             }
-            if (span <= kGridMaxCellsPerSphere) registrations += span;
         }
-        if (registrations <= 64.0 * in.size() + 1048576.0) break;
-        if (attempt == 16 || (nc[0] == 1 && nc[1] == 1 && nc[2] == 1)) { g.why = "grid too large"; return; }
-        h0 *= 1.5;
+        const double cell_words = static_cast<double>(n_zones) * (static_cast<double>(n_cells) + 1.0);
+        if (registrations <= 33554432.0 && cell_words <= 33554432.0) {
+            gridded.clear();
+            for (int i : in) { if (fat[i]) is_always[i] = 1; else gridded.push_back(i); }
+            break;
+        }
+        if (attempt == 24) { g.why = "grid too large"; return; }
+        if (n_zones > 1) { for (int k = 0; k < 3; ++k) zn[k] = std::max(1, zn[k] - 1); }      // fewer zones first, then coarser cells
+        else h0 *= 1.5;
     }
-    auto range = [&](int i, int k, int& a, int& b) {
-        const double c = k == 0 ? s->cx[i] : k == 1 ? s->cy[i] : s->cz[i];
-        a = static_cast<int>(std::floor((c - rbox[i] - lof[k]) / hf[k]));
-        b = static_cast<int>(std::floor((c + rbox[i] - lof[k]) / hf[k]));
-        a = std::max(0, std::min(nc[k] - 1, a));
-        b = std::max(0, std::min(nc[k] - 1, b));
-    };
-    const size_t n_cells = static_cast<size_t>(nc[0]) * nc[1] * nc[2];
-    std::vector<uint32_t> count(n_cells + 1, 0);
-    std::vector<int> gridded;
-    for (int i : in) {
-        int a[3], b[3];
-        for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
-        const double span = static_cast<double>(b[0] - a[0] + 1) * (b[1] - a[1] + 1) * (b[2] - a[2] + 1);
-        if (span > kGridMaxCellsPerSphere) { g.always.push_back(static_cast<uint32_t>(i)); continue; }
-        gridded.push_back(i);
-        for (int z = a[2]; z <= b[2]; ++z)
-            for (int y = a[1]; y <= b[1]; ++y)
-                for (int x = a[0]; x <= b[0]; ++x) ++count[(static_cast<size_t>(z) * nc[1] + y) * nc[0] + x + 1];
-    }
-    std::sort(g.always.begin(), g.always.end());
-    if (static_cast<int>(g.always.size()) > kGridMaxAlways) { g.why = "too many spheres that a grid cannot hold (non-finite, outliers, or spanning thousands of cells)"; return; }
-    for (size_t c = 0; c < n_cells; ++c) count[c + 1] += count[c];
-    if (count[n_cells] > 0x7FFFFFFFu) { g.why = "grid too large"; return; }
-    g.cell_start = count;
-    g.items.assign(std::max<size_t>(1, count[n_cells]), 0u);
-    std::vector<uint32_t> fill(count.begin(), count.end() - 1);
-    for (int i : gridded) {              // ascending sphere index, so every cell's items are ascending
-        int a[3], b[3];
-        for (int k = 0; k < 3; ++k) range(i, k, a[k], b[k]);
-        for (int z = a[2]; z <= b[2]; ++z)
-            for (int y = a[1]; y <= b[1]; ++y)
-                for (int x = a[0]; x <= b[0]; ++x) g.items[fill[(static_cast<size_t>(z) * nc[1] + y) * nc[0] + x]++] = static_cast<uint32_t>(i);
+    g.always.clear();
+    for (int i = 0; i < n; ++i) if (is_always[i]) g.always.push_back(static_cast<uint32_t>(i));
+    if (static_cast<int>(g.always.size()) > kGridMaxAlways) { g.why = "too many spheres that a grid cannot hold (outliers, or spanning thousands of cells)"; return; }
+    // CSR per zone: cell_start[zone * (n_cells + 1) + cell] indexes the shared items array
+    g.cell_start.assign(n_zones * (n_cells + 1), 0u);
+    std::vector<uint32_t> count(n_cells + 1);
+    size_t total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) g.items.assign(std::max<size_t>(1, total), 0u);
+        size_t base = 0;
+        for (int z = 0; z < static_cast<int>(n_zones); ++z) {
+            const int zi[3] = {z % zn[0], (z / zn[0]) % zn[1], z / (zn[0] * zn[1])};
+            double zl[3], zh[3];
+            zone_box(zi, zl, zh);
+            uint32_t* cs = g.cell_start.data() + static_cast<size_t>(z) * (n_cells + 1);
+            if (pass == 0) std::fill(count.begin(), count.end(), 0u);
+            else for (size_t c = 0; c < n_cells; ++c) count[c] = cs[c];          // fill cursors
+            for (int i : gridded) {                                             // ascending sphere index within every cell
+                const double rb = box_for_zone(i, zl, zh);
+                int a[3], b[3];
+                for (int k = 0; k < 3; ++k) range(i, rb, k, a[k], b[k]);
+                for (int zz = a[2]; zz <= b[2]; ++zz)
+                    for (int y = a[1]; y <= b[1]; ++y)
+                        for (int x = a[0]; x <= b[0]; ++x) {
+                            const size_t cell = (static_cast<size_t>(zz) * nc[1] + y) * nc[0] + x;
+                            if (pass == 0) ++count[cell + 1];
+                            else g.items[count[cell]++] = static_cast<uint32_t>(i);
+                        }
+            }
+            if (pass == 0) {
+                uint64_t run = base;
+                cs[0] = static_cast<uint32_t>(run);
+                for (size_t c = 0; c < n_cells; ++c) { run += count[c + 1]; cs[c + 1] = static_cast<uint32_t>(run); }
+                if (run > 0x7FFFFFFFull) { g.why = "grid too large"; return; }
+                base = static_cast<size_t>(run);
+                total = base;
+            }
+        }
     }
     if (g.always.empty()) g.always.push_back(0u);      // keep the array non-empty for the upload; n_always stays 0
     GridDev& d = g.dev;
@@ -326,11 +376,14 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
     d.hix = hif[0]; d.hiy = hif[1]; d.hiz = hif[2];
     d.hx = hf[0]; d.hy = hf[1]; d.hz = hf[2];
     d.ihx = ihf[0]; d.ihy = ihf[1]; d.ihz = ihf[2];
+    d.znx = zn[0]; d.zny = zn[1]; d.znz = zn[2];
+    d.izx = izs[0]; d.izy = izs[1]; d.izz = izs[2];
+    d.zone_stride = static_cast<int32_t>(n_cells + 1);
     d.cx = static_cast<float>(centre[0]); d.cy = static_cast<float>(centre[1]); d.cz = static_cast<float>(centre[2]);
     d.r_allow2 = static_cast<float>(r_allow * r_allow * (1.0 - 1e-5));
     d.slack = static_cast<float>(slack);
-    g.mean_items_per_cell = static_cast<double>(count[n_cells]) / static_cast<double>(n_cells);
-    g.mean_cells_per_sphere = gridded.empty() ? 0.0 : static_cast<double>(count[n_cells]) / static_cast<double>(gridded.size());
+    g.mean_items_per_cell = static_cast<double>(total) / static_cast<double>(n_cells * n_zones);
+    g.mean_cells_per_sphere = gridded.empty() ? 0.0 : static_cast<double>(total) / static_cast<double>(gridded.size() * n_zones);
     g.usable = true;
 }
 

