@@ -37,6 +37,22 @@ struct RenderArgs {
 // adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
 constexpr int kDequeue = 2;      // packets a wavefront draws from the queue per atomic
 
+// fp32 run sum -> signed 32.32 fixed point (two's complement in a u64), entirely in fp32/integer instructions (f64
+// conversions run at a fraction of the fp32 rate and this executes in nearly every pass).  Integer part = floor,
+// fraction rounded to nearest-even 2^-32; NaN contributes 0, magnitudes are clamped to +-2^30.  Any deterministic map
+// would do — integer accumulation is what makes the image independent of scheduling — this one is exact for every
+// non-negative sum (f - floor(f) and its scaling by 2^32 are exact in fp32).
+__device__ __forceinline__ unsigned long long to_fixed_32_32(float f) {
+    const float lim = 0x1p30f;
+    const float c = (f == f) ? fminf(fmaxf(f, -lim), lim) : 0.0f;
+    float hi = floorf(c);
+    float frac = c - hi;                       // [0, 1]; can round up to 1 only for tiny negative c
+    if (frac >= 1.0f) { hi += 1.0f; frac = 0.0f; }
+    const uint32_t lo = static_cast<uint32_t>(rintf(frac * 4294967296.0f));      // < 2^32
+    const uint32_t top = static_cast<uint32_t>(static_cast<int32_t>(hi));
+    return (static_cast<unsigned long long>(top) << 32) | lo;
+}
+
 template <bool LDS, bool GRID = false>
 __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect) {
     const int lane = isect.lane;
@@ -68,16 +84,11 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 start = true;
             } else {
                 if (has_unit) {
-                    // 32.32 fixed point; NaN contributes 0, magnitudes are clamped to +-2^30.
-                    const float lim = 0x1p30f;
-                    const float fr = fminf(fmaxf(acc.x, -lim), lim), fg = fminf(fmaxf(acc.y, -lim), lim), fb = fminf(fmaxf(acc.z, -lim), lim);
-                    const long long qr = (acc.x == acc.x) ? __double2ll_rn(static_cast<double>(fr) * 4294967296.0) : 0;
-                    const long long qg = (acc.y == acc.y) ? __double2ll_rn(static_cast<double>(fg) * 4294967296.0) : 0;
-                    const long long qb = (acc.z == acc.z) ? __double2ll_rn(static_cast<double>(fb) * 4294967296.0) : 0;
+                    const unsigned long long qr = to_fixed_32_32(acc.x), qg = to_fixed_32_32(acc.y), qb = to_fixed_32_32(acc.z);
                     unsigned long long* dst = A.accum + static_cast<size_t>(slot) * 3;
-                    atomicAdd(dst + 0, static_cast<unsigned long long>(qr));
-                    atomicAdd(dst + 1, static_cast<unsigned long long>(qg));
-                    atomicAdd(dst + 2, static_cast<unsigned long long>(qb));
+                    atomicAdd(dst + 0, qr);
+                    atomicAdd(dst + 1, qg);
+                    atomicAdd(dst + 2, qb);
                     has_unit = false;
                 }
                 need = true;
