@@ -75,8 +75,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        // one 32 x 32 -> 64 product each (v_mad_u64_u32) instead of separate low and high multiplies
+        const uint64_t p0 = static_cast<uint64_t>(M0) * c.x, p1 = static_cast<uint64_t>(M1) * c.z;
+        const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+        const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += W0;
         k.y += W1;

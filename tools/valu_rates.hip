@@ -22,10 +22,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         }                                                                                \
     } while (0)
 
-enum Op { FMA_F32, FMA_F32_SGPR, PK_FMA_F32, PK_FMA_F16, DOT2_F32_F16, DOT2C_F32_F16, DOT2_F32_BF16, ALIGNBIT, MIX_FORM1, MIX_FORM2, N_OPS };
+enum Op { FMA_F32, FMA_F32_SGPR, PK_FMA_F32, PK_FMA_F16, DOT2_F32_F16, DOT2C_F32_F16, DOT2_F32_BF16, ALIGNBIT, MIX_FORM1, MIX_FORM2, MUL_LO_U32, MUL_HI_U32, MAD_U64_U32, N_OPS };
 static const char* kNames[N_OPS] = {"v_fma_f32", "v_fma_f32 (SGPR src)", "v_pk_fma_f32", "v_pk_fma_f16", "v_dot2_f32_f16", "v_dot2c_f32_f16",
-                                    "v_dot2_f32_bf16", "v_alignbit_b32", "form 1 body: 8 fma + alignbit (per sphere)", "form 2 body: 8 pk_fma_f16 + shift + and (per PAIR)"};
-static const int kInstrPerRound[N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 72, 80};
+                                    "v_dot2_f32_bf16", "v_alignbit_b32", "form 1 body: 8 fma + alignbit (per sphere)", "form 2 body: 8 pk_fma_f16 + shift + and (per PAIR)",
+                                    "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32 (Philox product)"};
+static const int kInstrPerRound[N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 72, 80, 64, 64, 64};
 
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float seed_s) {
@@ -53,6 +54,9 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float 
                 if (OP == DOT2C_F32_F16) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[j]) : "v"(b), "v"(c));
                 if (OP == DOT2_F32_BF16) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(a[j]) : "v"(b), "v"(c));
                 if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(m) : "v"(a[j]));
+                if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b));
+                if (OP == MUL_HI_U32) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b));
+                if (OP == MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[j]) : "v"(b), "v"(c) : "vcc");
             }
         }
         if (OP == MIX_FORM1) {
@@ -145,6 +149,9 @@ int main(int argc, char** argv) {
     ms[ALIGNBIT] = run<ALIGNBIT>(d_out, grid, iters);
     ms[MIX_FORM1] = run<MIX_FORM1>(d_out, grid, iters);
     ms[MIX_FORM2] = run<MIX_FORM2>(d_out, grid, iters);
+    ms[MUL_LO_U32] = run<MUL_LO_U32>(d_out, grid, iters);
+    ms[MUL_HI_U32] = run<MUL_HI_U32>(d_out, grid, iters);
+    ms[MAD_U64_U32] = run<MAD_U64_U32>(d_out, grid, iters);
     std::printf("%s: %d CUs, %d wave(s) per SIMD, %d rounds\n", prop.name, n_cu, waves_per_simd, iters);
     const double base = ms[FMA_F32] * 1e6 / (static_cast<double>(iters) * 64 * waves_per_simd);
     for (int op = 0; op < N_OPS; ++op) {
