@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=(1, 2),
-                    help="2: consecutive frames alternate between two contexts/streams so that the tail of one frame's persistent kernel overlaps the "
-                         "start of the next (throughput experiment, DESIGN.md §7; per-kernel event times then include the overlap)")
+                    help="2: consecutive frames alternate between two contexts, each rendering on its own stream, so that the tail of one frame's "
+                         "persistent kernel overlaps the start of the next; gathers stay in order on one stream (throughput experiment, "
+                         "DESIGN.md §7; per-kernel event times then include the overlap)")
     ap.add_argument("--scene-k", type=int, default=0,
                     help="0: the stock 484-sphere scene (the metric's workload).  K > 0: BASELINE.json config 4, the same generator on a [-K,K)^2 grid (K=50: 10k spheres)")
     ap.add_argument("--accel", choices=("list", "grid"), default="list",
@@ -115,18 +116,18 @@ def main():
     if args.accel == "grid" and ctx.set_accel(rt.ACCEL_GRID) != rt.ACCEL_GRID:
         raise SystemExit("the grid was refused for this scene: " + rt.lib().rtk_last_error().decode())
     cam = rt.stock_camera(float(np.float32(args.width) / np.float32(args.height)))
-    sr = ShardedRenderer(ctx, args.width, args.height, rank, world, device)
-    ctxs, srs = [ctx], [sr]
+    ctxs = [ctx]
     for _ in range(1, args.frames_in_flight):
         c2 = rt.Context(local_rank)
         c2.set_scene(scene)
         if args.accel == "grid":
             c2.set_accel(rt.ACCEL_GRID)
         ctxs.append(c2)
-        srs.append(ShardedRenderer(c2, args.width, args.height, rank, world, device))
+    # one renderer: with several contexts it alternates them frame by frame, gathers stay on one stream in order
+    sr = ShardedRenderer(ctx, args.width, args.height, rank, world, device, extra_contexts=ctxs[1:])
 
     def step(i):
-        srs[i % len(srs)].render(cam, args.spp, args.depth, seed=i)
+        sr.render(cam, args.spp, args.depth, seed=i)
 
     def fence():
         torch.cuda.synchronize()

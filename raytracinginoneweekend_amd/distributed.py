@@ -32,27 +32,43 @@ def gather_tiles(local_tiles: torch.Tensor, group=None) -> torch.Tensor:
 
 
 class ShardedRenderer:
-    """Persistent per-rank state: context, tile buffer, gathered buffer, image.
+    """Persistent per-rank state: context(s), tile buffer(s), gathered buffer, image.
 
-    All GPU work of a frame — render kernel, finalise, all_gather, de-interleave — is queued on ONE torch stream
-    (`self.stream`, a non-default stream whose handle is given to the context): the collective is issued under
-    `torch.cuda.stream(self.stream)`, so RCCL orders it after the kernels that fill the tile buffer and before the
-    kernel that reads the gathered one.  (torch's default stream has handle 0, which rtk_context_set_stream
-    reads as "use the context's own stream": work on it would NOT be ordered against torch's collectives.)
+    The collective and the de-interleave of every frame are queued on ONE torch stream (`self.stream`, a non-default
+    stream): the collective is issued under `torch.cuda.stream(self.stream)`, so RCCL orders it after the kernels that
+    fill the tile buffer and before the kernel that reads the gathered one, and all collectives of a process are issued
+    in program order on one stream.  (torch's default stream has handle 0, which rtk_context_set_stream reads as "use
+    the context's own stream": work on it would NOT be ordered against torch's collectives.)
+
+    With one context (the default) the render kernel is queued on that same stream.  With `extra_contexts`
+    (experiment, bench.py --frames-in-flight 2) consecutive frames alternate between contexts, each rendering on a
+    stream of its own, tied to the shared stream by events: the persistent kernel of frame i+1 starts filling the CUs
+    that the tail of frame i leaves idle, while gathers still run one after another on `self.stream`.
     """
 
-    def __init__(self, ctx: Context, W: int, H: int, rank: int, world: int, device: torch.device, tile_w: int = 8, tile_h: int = 8):
+    def __init__(self, ctx: Context, W: int, H: int, rank: int, world: int, device: torch.device, tile_w: int = 8, tile_h: int = 8,
+                 extra_contexts=()):
         self.ctx, self.W, self.H, self.rank, self.world = ctx, W, H, rank, world
         self.tile_w, self.tile_h = tile_w, tile_h
         self.device = device
         self.tprp = tiles_per_rank_padded(W, H, world, tile_w, tile_h)
-        self.local = torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.float32, device=device)
+        self.ctxs = [ctx, *extra_contexts]
+        self.locals = [torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.float32, device=device) for _ in self.ctxs]
+        self.local = self.locals[0]
         self.image = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
         self.local_u8 = None     # allocated on the first render(..., output="u8")
         self.image_u8 = None
         self.stream = torch.cuda.Stream(device=device)
         self.stream.wait_stream(torch.cuda.current_stream(device))     # the zero-fills above
         assert self.stream.cuda_stream != 0
+        # one context: everything on self.stream.  Several: each renders on its own stream
+        self.render_streams = [self.stream] if len(self.ctxs) == 1 else [torch.cuda.Stream(device=device) for _ in self.ctxs]
+        for rs in self.render_streams:
+            if rs is not self.stream:
+                rs.wait_stream(torch.cuda.current_stream(device))
+        self._rendered = [None] * len(self.ctxs)     # events: tile buffer j filled / consumed by the gather
+        self._consumed = [None] * len(self.ctxs)
+        self._frame = 0
         ctx.set_stream(self.stream.cuda_stream)
         self._keep = None
 
@@ -60,28 +76,47 @@ class ShardedRenderer:
         return make_params(self.W, self.H, spp, depth, seed, 0.001, self.rank, self.world, self.tile_w, self.tile_h, run_len)
 
     def render(self, cam22, spp: int, depth: int, seed: int = 0, want_stats: bool = False, assemble: bool = True, output: str = "f32"):
-        """Render this rank's tiles, gather, de-interleave (asynchronous on self.stream).  Returns stats (or None);
+        """Render this rank's tiles, gather, de-interleave (asynchronous).  Returns stats (or None);
         the image is self.image (output="f32": colour sums) or self.image_u8 (output="u8": every rank applies
         write_color_binary to its own tiles first, so the gather moves a quarter of the bytes)
         once self.stream has been synchronised."""
         if output not in ("f32", "u8"):
             raise ValueError("output must be 'f32' or 'u8'")
         p = self.params(spp, depth, seed)
+        j = self._frame % len(self.ctxs)
+        self._frame += 1
+        ctx, local, rs = self.ctxs[j], self.locals[j], self.render_streams[j]
+        with torch.cuda.stream(rs):
+            if rs is not self.stream and self._consumed[j] is not None:
+                rs.wait_event(self._consumed[j])         # the gather of the frame that last used this tile buffer
+            ctx.set_stream(rs.cuda_stream)
+            st = ctx.render_tiles_device(cam22, p, local.data_ptr(), want_stats)
+            if rs is not self.stream:
+                self._rendered[j] = torch.cuda.Event()
+                self._rendered[j].record(rs)
+        if not assemble:
+            return st
         with torch.cuda.stream(self.stream):
+            if rs is not self.stream:
+                self.stream.wait_event(self._rendered[j])
+                ctx.set_stream(self.stream.cuda_stream)  # quantise / de-interleave of this frame go behind its gather
             if output == "u8" and self.local_u8 is None:
                 self.local_u8 = torch.zeros((self.tprp, TILE_PIXELS, 3), dtype=torch.uint8, device=self.device)
                 self.image_u8 = torch.zeros((self.H, self.W, 3), dtype=torch.uint8, device=self.device)
-            st = self.ctx.render_tiles_device(cam22, p, self.local.data_ptr(), want_stats)
-            if assemble and output == "f32":
-                gathered = gather_tiles(self.local)
-                self.ctx.deinterleave_device(gathered.data_ptr(), self.tprp, p, self.image.data_ptr())
-                self._keep = gathered   # keep the buffer alive until the next frame has been queued behind this one
-            elif assemble:
-                self.ctx.quantise_device(self.local.data_ptr(), self.tprp * TILE_PIXELS, spp, self.local_u8.data_ptr())
+            if output == "f32":
+                gathered = gather_tiles(local)
+                ctx.deinterleave_device(gathered.data_ptr(), self.tprp, p, self.image.data_ptr())
+            else:
+                ctx.quantise_device(local.data_ptr(), self.tprp * TILE_PIXELS, spp, self.local_u8.data_ptr())
                 gathered = gather_tiles(self.local_u8)
-                self.ctx.deinterleave_u8_device(gathered.data_ptr(), self.tprp, p, self.image_u8.data_ptr())
-                self._keep = gathered
+                ctx.deinterleave_u8_device(gathered.data_ptr(), self.tprp, p, self.image_u8.data_ptr())
+            self._keep = gathered   # keep the buffer alive until the next frame has been queued behind this one
+            if rs is not self.stream:
+                self._consumed[j] = torch.cuda.Event()
+                self._consumed[j].record(self.stream)
         return st
 
     def synchronize(self) -> None:
+        for rs in self.render_streams:
+            rs.synchronize()
         self.stream.synchronize()

@@ -44,11 +44,13 @@ class FakeCtx:
 
 
 class FakeRenderer:
-    def __init__(self, ctx, W, H, rank, world, device):
-        self.ctx = ctx
+    def __init__(self, ctx, W, H, rank, world, device, extra_contexts=()):
+        self.ctxs = [ctx, *extra_contexts]
+        self.n = 0
 
     def render(self, cam, spp, depth, seed=0):
-        self.ctx.frames += 1
+        self.ctxs[self.n % len(self.ctxs)].frames += 1
+        self.n += 1
 
 
 @pytest.fixture()
