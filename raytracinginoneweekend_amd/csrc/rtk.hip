@@ -1,6 +1,7 @@
 // rtk.hip — kernels and C ABI of librtk.so (see include/rtk.h for the contract and the reference
 // citations of every entry point).  gfx950 only; compiled with -ffp-contract=off (rtk_device.hpp).
 #include "rtk_device.hpp"
+#include "rtk_intersect.hpp"
 #include "rtk_render.hpp"
 #include "rtk_scene_prep.hpp"
 

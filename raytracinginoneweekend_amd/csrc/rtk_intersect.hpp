@@ -1,0 +1,516 @@
+// rtk_intersect.hpp — the closest-hit machinery of the render and intersect kernels: filter forms, compaction,
+// exact stage (Intersector::closest_hit) and the uniform-grid walk (Intersector::closest_hit_grid).
+// Device code; also built for the CPU by tests/cpu_emul.  Math, RNG, scene structs and the exact ray-sphere test are in
+// rtk_device.hpp; the per-wave render loop that calls this is rtk_render.hpp.
+#pragma once
+
+#include "rtk_device.hpp"
+
+namespace rtk {
+
+// Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
+//
+// Stage 1 (filter, all spheres, pure VALU): a conservative sign test of a widened discriminant in
+// normalised-direction form, 11 VALU instructions per sphere, every lane of the wavefront testing the
+// same sphere (operands broadcast from LDS, or from scalar/global loads when !LDS).  The sign bits
+// are funnel-shifted into one mask word per 32 spheres.
+// Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
+// Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
+// against its running `closest`; ascending order reproduces the reference's tie rule (a later
+// sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
+#ifndef RTK_FILTER_FORM
+#define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test),
+                               // 2 (experiment build): packed-f16 projection form (5 / test) where the scene allows, else form 1
+#endif
+
+// RTK_SMEM=1 (experiment build, NOT the shipped default, never timed yet): the filter reads its sphere operands
+// with scalar loads from the GLOBAL copy of `filt` through the constant address space, so they arrive as SGPR
+// operands: no LDS traffic and no broadcast VGPR writes.  The pointer cast is only ever applied to `filt_global`
+// (device global memory, read-only for the kernel's lifetime) — never to an LDS address.
+#ifndef RTK_SMEM
+#define RTK_SMEM 0
+#endif
+#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
+typedef float rtk_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
+#define RTK_FILT_LOAD(i) (reinterpret_cast<rtk_const_f4_ptr>(reinterpret_cast<uintptr_t>(filt_global))[i])
+#else
+#define RTK_FILT_LOAD(i) (filt[i])
+#endif
+
+// Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
+#ifdef RTK_HOST_EMULATION
+#define RTK_SCHED_BARRIER() ((void)0)
+#else
+#define RTK_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// RTK_STAGED_LARGE=1 (experiment build, default off until it has run on a GPU): scenes beyond kMaxLdsSpheres stream
+// the sphere list through a wave-private LDS chunk instead of reading every sphere with a broadcast global load.
+#ifndef RTK_STAGED_LARGE
+#define RTK_STAGED_LARGE 0
+#endif
+constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 32)
+#ifdef RTK_HOST_EMULATION
+#define RTK_WAVE_SYNC() ((void)__ballot(true))      // the fibers of a wave are not in lockstep between votes
+#else
+#define RTK_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
+
+// Uniform grid over the scene (no counterpart in the reference, whose HittableList::hit is O(N)).
+// Built on the host (rtk_scene_prep.hpp build_grid); opt-in (rtk_context_set_accel), for lists far beyond LDS size.
+// Every "gridable" sphere is registered in each cell its box overlaps, the box being inflated by everything the
+// reference's rounding could still accept for ray origins inside the ball (centre, r_allow); the few spheres that
+// are not gridable (non-finite, outliers such as the 1000-unit ground sphere) are tested for every ray.
+struct GridDev {
+    const uint32_t* cell_start;   // [zones][nx*ny*nz + 1]: one registration per zone of ray origins
+    const uint32_t* items;        // sphere indices, ascending within a cell
+    const uint32_t* always;       // [n_always] ascending: spheres outside the grid
+    int32_t n_always;
+    int32_t nx, ny, nz;
+    float lox, loy, loz;          // grid box
+    float hix, hiy, hiz;
+    float hx, hy, hz;             // cell size
+    float ihx, ihy, ihz;          // 1 / cell size
+    int32_t znx, zny, znz;        // origin zones over the grid box (outer zones extend outwards)
+    float izx, izy, izz;          // zones per unit length
+    int32_t zone_stride;          // nx*ny*nz + 1
+    float cx, cy, cz, r_allow2;   // ray origins inside this ball may use the grid; others take the brute-force path
+    float slack;                  // distance by which traversal decisions are widened (float error of the walk)
+};
+
+template <bool LDS>
+struct Intersector {
+    const float4* filt;    // LDS or global
+    const float4* filt_global;   // always the global-memory copy (RTK_SMEM reads through it)
+    const float4* exact;   // LDS or global (cx, cy, cz, r*r)
+    const uint32_t* always = nullptr;   // RTK_FILTER_FORM == 2: SceneDev::always_mask (global; read with wave-uniform indices)
+    uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
+    float4* stage = nullptr;     // RTK_STAGED_LARGE: this wave's LDS chunk of kStageSpheres filter operands
+    FilterBounds fb;
+    int n;
+    int lane;
+#ifdef RTK_HOST_EMULATION
+    uint8_t* dbg_flags = nullptr;   // emulation only: [n] set to 1 for every sphere the filter passes to the exact stage
+#endif
+
+    // `list_base`: list entries are 16-bit offsets from it (the list is flushed before an offset could overflow).
+    __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int list_base, int& cnt, float& closest, int& best,
+                                          uint32_t& n_exact) const {
+        for (int k = 0; wave_any(k < cnt); ++k) {
+            RTK_STAT(lane, flush_iters);
+            if (k < cnt) {
+                const int j = list_base + static_cast<int>(list[k * kWave + lane]);
+                const float4 s = exact[j];
+                float root;
+                if (sphere_root_exact(r, a, s, t_min, closest, root)) {
+                    closest = root;
+                    best = j;
+                }
+                ++n_exact;
+            }
+        }
+        cnt = 0;
+    }
+
+    // Per-ray operands of the filter.
+    struct FilterRay {
+#if RTK_FILTER_FORM == 0
+        float ox, oy, oz, dhx, dhy, dhz;
+#else
+        float e1x, e1y, e1z, ns1, e2x, e2y, e2z, ns2;
+#endif
+#if RTK_FILTER_FORM == 2
+        H2 a1, b1, c1, n1, a2, b2, c2, n2;     // e1 / e2 components in chain order and -o.e, shrunk by g, each in both halves
+#endif
+    };
+
+#if RTK_FILTER_FORM == 2
+    // `always` is SceneDev::always_mask: device GLOBAL memory, read-only while a kernel runs, indexed by a wave-uniform
+    // word number — read with a scalar load (constant address space) so it costs no vector register.  (Never apply
+    // this cast to an LDS pointer.)
+#ifdef RTK_HOST_EMULATION
+#define RTK_ALWAYS_LOAD(w) (always[w])
+#else
+#define RTK_ALWAYS_LOAD(w) (reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(always))[w])
+#endif
+#ifndef RTK_PAIR_GROUP
+#define RTK_PAIR_GROUP 2
+#endif
+    static constexpr int kPairGroup = RTK_PAIR_GROUP;     // pairs processed together (2 or 4; more = more registers)
+    // Packed-f16 form: TWO spheres per register (one in each half), 10 instructions per pair = 5 per test:
+    // 2 x 3 v_pk_fma_f16 for the two projections, 2 v_pk_fma_f16 for p1^2 + p2^2 - rho^2, then the two sign bits
+    // (bits 31 and 15) are rotated to their place in the word's mask and merged (v_alignbit_b32, v_and_or_b32).
+    // rec = (c_hat[ax0], c_hat[ax1], c_hat[ax2], -rho^2), each dword holding the value for both spheres of the pair.
+    static __device__ __forceinline__ uint32_t filter_pair_f16(const FilterRay& f, float rx, float ry, float rz, float rw) {
+        const H2 ca = h2_from_bits(rx), cb = h2_from_bits(ry), cc = h2_from_bits(rz), k = h2_from_bits(rw);
+        const H2 p1 = h2_fma(cc, f.c1, h2_fma(cb, f.b1, h2_fma(ca, f.a1, f.n1)));
+        const H2 p2 = h2_fma(cc, f.c2, h2_fma(cb, f.b2, h2_fma(ca, f.a2, f.n2)));
+        return h2_bits(h2_fma(p2, p2, h2_fma(p1, p1, k)));
+    }
+#endif
+
+    // One ray-sphere filter test; shifts the result bit into `m` (form 0: 1 = certainly missed, form 1: 1 = candidate).
+    static __device__ __forceinline__ void filter_one(const FilterRay& f, float sx, float sy, float sz, float sw, uint32_t& m) {
+#if RTK_FILTER_FORM == 0
+        const float x = f.ox - sx, y = f.oy - sy, z = f.oz - sz;
+        const float hb = fmaf(z, f.dhz, fmaf(y, f.dhy, x * f.dhx));
+        const float c = fmaf(z, z, fmaf(y, y, fmaf(x, x, -sw)));
+        const float disc = fmaf(hb, hb, -c);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(disc), 31);
+#else
+        const float p1 = fmaf(sz, f.e1z, fmaf(sy, f.e1y, fmaf(sx, f.e1x, f.ns1)));
+        const float p2 = fmaf(sz, f.e2z, fmaf(sy, f.e2y, fmaf(sx, f.e2x, f.ns2)));
+        const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
+#endif
+    }
+
+    __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
+                                                uint32_t& n_exact) const {
+        // Reference `a` (Sphere3.hpp:33), hoisted.
+        const float a = length_squared(r.d);
+        // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
+        // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
+        const float big = 0x1p30f;
+        bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+        FilterRay f;
+        const float inv_len = __builtin_amdgcn_rsqf(a);
+#if RTK_FILTER_FORM == 0
+        // d-hat widened by (1+2^-15).  v_rsq_f32 is 1 ulp; its error is far inside the margin.
+        f.ox = r.o.x; f.oy = r.o.y; f.oz = r.o.z;
+        f.dhx = r.d.x * (inv_len * kFilterScale); f.dhy = r.d.y * (inv_len * kFilterScale); f.dhz = r.d.z * (inv_len * kFilterScale);
+#else
+        // Orthonormal basis (e1, e2) of the plane perpendicular to the ray (Duff et al. 2017, branch-free);
+        // a sphere can only be hit if its centre, projected on that plane, lies within r of the ray.
+        // The projected distances are shrunk by g < 1 so that everything the reference's own rounding could
+        // still accept (E) and this filter's evaluation error (dp) stay inside r.
+        const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
+        const float sg = copysignf(1.0f, dz);
+        const float aa = -__builtin_amdgcn_rcpf(sg + dz);
+        const float bb = dx * dy * aa;
+        const float u1x = fmaf(sg * dx, dx * aa, 1.0f), u1y = sg * bb, u1z = -sg * dx;     // unshrunk basis
+        const float u2x = bb, u2y = fmaf(dy, dy * aa, sg), u2z = -dy;
+#if RTK_FILTER_FORM == 2
+        if (fb.f16_ok) {
+            // Filter space: recentred and scaled by a power of two (binary16 has 5 exponent bits).
+            const float ox = (r.o.x - fb.cen[0]) * fb.scale, oy = (r.o.y - fb.cen[1]) * fb.scale, oz = (r.o.z - fb.cen[2]) * fb.scale;
+            const float o_len = __builtin_amdgcn_sqrtf(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));
+            const float M = o_len + fb.c_max_s;
+            const float E = 0x1p-19f * fmaf(M, M, fb.r_max2_s);
+            const float dp = 0x1p-19f * M;
+            // coordinates in chain order (a scene-wide permutation: largest extent first, smallest last)
+            auto pick = [](float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); };
+            const float a1 = pick(u1x, u1y, u1z, fb.ax[0]), b1 = pick(u1x, u1y, u1z, fb.ax[1]), c1 = pick(u1x, u1y, u1z, fb.ax[2]);
+            const float a2 = pick(u2x, u2y, u2z, fb.ax[0]), b2 = pick(u2x, u2y, u2z, fb.ax[1]), c2 = pick(u2x, u2y, u2z, fb.ax[2]);
+            const float oa = pick(ox, oy, oz, fb.ax[0]), ob = pick(ox, oy, oz, fb.ax[1]), oc = pick(ox, oy, oz, fb.ax[2]);
+            // binary16 error of one projected coordinate of a sphere that matters (|p| <= r~), per unit of g
+            // (DESIGN.md §4.1 form 2): basis quantisation u M, rounding of -o.e, and the three chain roundings
+            // u (3|p| + 2|t_last| + |t_mid|); the 3|p| part, subnormal steps and the roundings of p^2 - rho^2 are
+            // inside the per-sphere rho.
+            const float n1 = fabsf(fmaf(oc, c1, fmaf(ob, b1, oa * a1))), n2 = fabsf(fmaf(oc, c2, fmaf(ob, b2, oa * a2)));
+            const float k1 = n1 + fmaf(2.0f * fb.cmax_s[2], fabsf(c1), fb.cmax_s[1] * fabsf(b1));
+            const float k2 = n2 + fmaf(2.0f * fb.cmax_s[2], fabsf(c2), fb.cmax_s[1] * fabsf(b2));
+            const float d16 = (1.03f * 0x1p-11f) * (M + fmaxf(k1, k2));
+            const float g = fb.r_min_s * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min_s, fb.r_min_s, E)) + 2.0f * (dp + d16)) * (1.0f - 0x1p-16f);
+            safe = safe && (o_len < 0x1p15f) && (g > 0x1p-6f);      // |o.e| stays below binary16's 65504; below that g the margins stop scaling with g
+            f.a1 = h2_splat(g * a1); f.b1 = h2_splat(g * b1); f.c1 = h2_splat(g * c1);
+            f.a2 = h2_splat(g * a2); f.b2 = h2_splat(g * b2); f.c2 = h2_splat(g * c2);
+            // -o.e against the QUANTISED basis, so that only its own rounding to binary16 remains
+            f.n1 = h2_splat(-fmaf(oc, h2_lo(f.c1), fmaf(ob, h2_lo(f.b1), oa * h2_lo(f.a1))));
+            f.n2 = h2_splat(-fmaf(oc, h2_lo(f.c2), fmaf(ob, h2_lo(f.b2), oa * h2_lo(f.a2))));
+        } else
+#endif
+        {
+            const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
+            const float M = o_len + fb.c_max;
+            const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
+            const float dp = 0x1p-19f * M;
+            const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
+            f.e1x = g * u1x; f.e1y = g * u1y; f.e1z = g * u1z;
+            f.e2x = g * u2x; f.e2y = g * u2y; f.e2z = g * u2z;
+            f.ns1 = -fmaf(r.o.z, f.e1z, fmaf(r.o.y, f.e1y, r.o.x * f.e1x));
+            f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
+        }
+#endif
+        RTK_STAT(lane, closest_hit_calls);
+        float closest = t_max;
+        int best = -1;
+        int cnt = 0;
+        int list_base = 0;       // wave-uniform
+
+        // compaction: candidate bits (MSB = first sphere of the word) -> this lane's list, ascending index;
+        // when a lane's list is full the wave runs the exact stage early and carries on
+        auto emit = [&](int base, uint32_t cand) {
+#ifdef RTK_HOST_EMULATION
+            if (dbg_flags)
+                for (int b = 0; b < 32; ++b)
+                    if (cand & (0x80000000u >> b)) dbg_flags[base + b] = 1;
+#endif
+            for (;;) {
+                while (wave_any(cand != 0 && cnt < kListCap)) {
+                    RTK_STAT(lane, compact_iters);
+                    if (cand != 0 && cnt < kListCap) {
+                        const int pos = __clz(static_cast<int>(cand));
+                        cand &= ~(0x80000000u >> pos);
+                        list[cnt * kWave + lane] = static_cast<uint16_t>(base + pos - list_base);
+                        ++cnt;
+                    }
+                }
+                if (!wave_any(cand != 0)) break;
+                RTK_STAT(lane, early_flushes);
+                flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+            }
+        };
+        auto to_cand = [&](uint32_t m, uint32_t valid) -> uint32_t {
+#if RTK_FILTER_FORM == 0
+            m = ~m;
+#endif
+            uint32_t cand = (safe ? m : 0xFFFFFFFFu) & valid;
+            return active ? cand : 0u;
+        };
+
+        // filter + compaction over `count` consecutive spheres starting at list index `base`; load(i) yields the
+        // operands of sphere base + i
+        auto scan = [&](auto&& load, int base, int count) {
+            const int full = count >> 5, rem = count & 31;
+            for (int w = 0; w < full; ++w) {
+                if (base + w * 32 - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
+                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                    list_base = base + w * 32;
+                }
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const auto s = load(w * 32 + i);
+                    filter_one(f, s.x, s.y, s.z, s.w, m);
+                }
+                RTK_STAT(lane, filter_words);
+                emit(base + w * 32, to_cand(m, 0xFFFFFFFFu));
+            }
+            if (rem) {
+                uint32_t m = 0;
+#pragma unroll 4
+                for (int i = 0; i < rem; ++i) {
+                    const auto s = load(full * 32 + i);
+                    filter_one(f, s.x, s.y, s.z, s.w, m);
+                }
+                m <<= (32 - rem);
+                emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+            }
+        };
+#if RTK_FILTER_FORM == 2
+        // Pair records: word w of 32 spheres owns records [16 w, 16 w + 16); in a word of `cnt` spheres, pair k holds
+        // sphere k in its HIGH halves and sphere np + k in its LOW halves, np = ceil(cnt / 2) — so that after np steps the
+        // mask has the first np spheres in bits 31.. and the rest in bits 15.. (for a full word that IS the usual
+        // MSB-first order; a partial last word shifts its low half up).
+        auto scan_pairs = [&](auto&& loadq, int count) {
+            const int full = count >> 5, rem = count & 31, last_word = (count - 1) >> 5;
+            uint32_t aw = RTK_ALWAYS_LOAD(0);     // the always-mask of word w is requested one word ahead
+            for (int w = 0; w < full; ++w) {
+                if (w * 32 - list_base > 65535 - 64) {
+                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                    list_base = w * 32;
+                }
+                uint32_t m = aw;
+                aw = RTK_ALWAYS_LOAD(w < last_word ? w + 1 : w);
+                // kPairGroup pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one
+                // between them on gfx950), with the next group's records already requested
+                typedef decltype(loadq(0)) Rec;
+                Rec q[kPairGroup];
+#pragma unroll
+                for (int j = 0; j < kPairGroup; ++j) q[j] = loadq(w * 16 + j);
+#pragma unroll
+                for (int g = 0; g < 16 / kPairGroup; ++g) {
+                    // last group: re-reads itself, never beyond the word
+                    const int nx = w * 16 + kPairGroup * (g + 1 < 16 / kPairGroup ? g + 1 : g);
+                    Rec nq[kPairGroup];
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
+                    RTK_SCHED_BARRIER();      // keep these requests ahead of the arithmetic on the previous group
+                    H2 x[kPairGroup], y[kPairGroup];
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].y), f.b1, x[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].y), f.b2, y[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].z), f.c1, x[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].z), f.c2, y[j]);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(x[j], x[j], h2_from_bits(q[j].w));
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) {
+                        const int k = kPairGroup * g + j;
+                        m |= (h2_bits(h2_fma(y[j], y[j], x[j])) >> k) & (0x80008000u >> k);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) q[j] = nq[j];
+                }
+                RTK_STAT(lane, filter_words);
+                emit(w * 32, to_cand(m, 0xFFFFFFFFu));
+            }
+            if (rem) {
+                const int np = (rem + 1) >> 1;
+                uint32_t m = 0;
+#pragma unroll 2
+                for (int k = 0; k < np; ++k) {
+                    const auto q = loadq(full * 16 + k);
+                    const uint32_t d = filter_pair_f16(f, q.x, q.y, q.z, q.w);
+                    m |= __builtin_amdgcn_alignbit(d, d, k) & (0x80008000u >> k);
+                }
+                m = ((m & 0xFFFF0000u) | ((m & 0xFFFFu) << (16 - np))) | aw;
+                emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+            }
+        };
+        if (fb.f16_ok) {
+            scan_pairs([&](int j) { return RTK_FILT_LOAD(j); }, n);
+        } else
+#endif
+#if RTK_STAGED_LARGE
+        if (!LDS) {
+            // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced
+            // global load per 64 spheres instead of one broadcast load per sphere — and filters from LDS as usual.
+            // Only this wave touches `stage`; DS operations of a wave execute in order, so the chunk's writes are
+            // visible to its reads and the next chunk's writes cannot overtake this chunk's reads.
+            // The next chunk is fetched into registers before the current one is scanned, so its
+            // latency hides behind ~1150 filter instructions.
+            constexpr int kPerLane = kStageSpheres / kWave;
+#ifdef RTK_HOST_EMULATION
+            typedef float4 Quad;
+#else
+            typedef float Quad __attribute__((ext_vector_type(4)));     // a register quad the compiler keeps out of scratch
+#endif
+            const Quad* src = reinterpret_cast<const Quad*>(filt);
+            Quad* dst = reinterpret_cast<Quad*>(stage);
+            Quad pre[kPerLane];
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                const int i = j * kWave + lane;
+                pre[j] = src[i < n ? i : n - 1];
+            }
+            for (int base = 0; base < n; base += kStageSpheres) {
+                const int count = n - base < kStageSpheres ? n - base : kStageSpheres;
+                RTK_WAVE_SYNC();
+#pragma unroll
+                for (int j = 0; j < kPerLane; ++j)
+                    if (j * kWave + lane < count) dst[j * kWave + lane] = pre[j];
+                RTK_WAVE_SYNC();
+#pragma unroll
+                for (int j = 0; j < kPerLane; ++j) {          // unconditional (clamped) loads: no branch, so no wait before the scan
+                    const int i = base + kStageSpheres + j * kWave + lane;
+                    pre[j] = src[i < n ? i : n - 1];
+                }
+                scan([&](int i) { return stage[i]; }, base, count);
+            }
+        } else
+#endif
+        {
+            scan([&](int i) { return RTK_FILT_LOAD(i); }, 0, n);
+        }
+        flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+        t_out = closest;
+        idx_out = best;
+    }
+
+    // Closest hit through the uniform grid: same result as closest_hit(), bit for bit.
+    // For a finite ray and range the reference's answer does not depend on the order the spheres are visited in:
+    // a sphere's root is chosen against t_min alone whenever it could still win, so the list walk of
+    // HittableList.hpp:34-38 yields (min root, then max index).  Lanes whose ray or range is not finite, or whose
+    // origin lies outside the ball the grid's margins were sized for, take the brute-force path afterwards.
+    __device__ __forceinline__ void closest_hit_grid(const GridDev& G, const Ray& r, bool active, float t_min, float t_max, float& t_out,
+                                                     int& idx_out, uint32_t& n_exact) const {
+        const float a = length_squared(r.d);
+        const float big = 0x1p30f;
+        const float qx = r.o.x - G.cx, qy = r.o.y - G.cy, qz = r.o.z - G.cz;
+        // |d|^2 < 2^60: with every sphere below 2^30 (build_grid) no intermediate of the exact test overflows, so all
+        // roots are finite numbers — the condition under which the visiting order does not matter
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p60f) &&
+                          (fmaf(qx, qx, fmaf(qy, qy, qz * qz)) <= G.r_allow2) && (t_min == t_min) && (t_max == t_max);
+        const bool use = active && safe;
+        float closest = t_max;
+        int best = -1;
+        auto test = [&](int j) {
+            const float4 s = exact[j];
+            float root;
+            if (sphere_root_exact(r, a, s, t_min, closest, root) && (root < closest || j > best)) {
+                closest = root;
+                best = j;
+            }
+            ++n_exact;
+        };
+        for (int k = 0; k < G.n_always; ++k) {             // the same sphere on every lane: broadcast loads
+            const int j = static_cast<int>(G.always[k]);
+            if (use) test(j);
+        }
+        if (use) {
+            const float len = __builtin_amdgcn_sqrtf(a);
+            const float slack_t = 1.01f * G.slack * __builtin_amdgcn_rcpf(len);
+            const float tiny = 0x1p-60f * len;             // a component this small cannot leave a cell within the scene
+            const bool mx = fabsf(r.d.x) > tiny, my = fabsf(r.d.y) > tiny, mz = fabsf(r.d.z) > tiny;
+            const float inf = __builtin_inff();
+            const float ivx = mx ? 1.0f / r.d.x : inf, ivy = my ? 1.0f / r.d.y : inf, ivz = mz ? 1.0f / r.d.z : inf;
+            // clip [t_min - slack, closest + slack] against the grid box
+            float t0 = t_min - slack_t, t1 = closest + slack_t;
+            bool miss = false;
+            if (mx) { const float ta = (G.lox - r.o.x) * ivx, tb = (G.hix - r.o.x) * ivx; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.x < G.lox || r.o.x > G.hix;
+            if (my) { const float ta = (G.loy - r.o.y) * ivy, tb = (G.hiy - r.o.y) * ivy; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.y < G.loy || r.o.y > G.hiy;
+            if (mz) { const float ta = (G.loz - r.o.z) * ivz, tb = (G.hiz - r.o.z) * ivz; t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb)); }
+            else miss = miss || r.o.z < G.loz || r.o.z > G.hiz;
+            if (!miss && t0 <= t1 + slack_t) {
+                auto cell_of = [](float p, float lo, float ih, int n) {
+                    const float f = floorf((p - lo) * ih);
+                    return !(f >= 0.0f) ? 0 : (f > static_cast<float>(n - 1) ? n - 1 : static_cast<int>(f));   // NaN and negatives -> 0
+                };
+                // the registration made for origins like this one
+                const uint32_t* cs = G.cell_start + static_cast<size_t>((cell_of(r.o.z, G.loz, G.izz, G.znz) * G.zny + cell_of(r.o.y, G.loy, G.izy, G.zny)) * G.znx +
+                                                                        cell_of(r.o.x, G.lox, G.izx, G.znx)) * static_cast<size_t>(G.zone_stride);
+                int ix = cell_of(fmaf(t0, r.d.x, r.o.x), G.lox, G.ihx, G.nx);
+                int iy = cell_of(fmaf(t0, r.d.y, r.o.y), G.loy, G.ihy, G.ny);
+                int iz = cell_of(fmaf(t0, r.d.z, r.o.z), G.loz, G.ihz, G.nz);
+                const int sx = r.d.x > 0.0f ? 1 : -1, sy = r.d.y > 0.0f ? 1 : -1, sz = r.d.z > 0.0f ? 1 : -1;
+                // every step moves one cell forward along one axis, so the walk ends after at most nx + ny + nz steps
+                for (int steps = G.nx + G.ny + G.nz; steps > 0; --steps) {
+                    const int cell = (iz * G.ny + iy) * G.nx + ix;
+                    const uint32_t b = cs[cell], e = cs[cell + 1];
+                    for (uint32_t q = b; q < e; ++q) test(static_cast<int>(G.items[q]));
+                    // parameter at which the ray leaves this cell, per axis (recomputed from the cell index: no drift)
+                    const float ex = mx ? (fmaf(static_cast<float>(ix + (sx > 0 ? 1 : 0)), G.hx, G.lox) - r.o.x) * ivx : inf;
+                    const float ey = my ? (fmaf(static_cast<float>(iy + (sy > 0 ? 1 : 0)), G.hy, G.loy) - r.o.y) * ivy : inf;
+                    const float ez = mz ? (fmaf(static_cast<float>(iz + (sz > 0 ? 1 : 0)), G.hz, G.loz) - r.o.z) * ivz : inf;
+                    const float t_exit = fminf(ex, fminf(ey, ez));
+                    // nothing beyond closest (or beyond the clipped range) can win; both widened by the slack
+                    if (!(t_exit - slack_t <= fminf(closest, t1))) break;
+                    if (ex <= ey && ex <= ez) { ix += sx; if (ix < 0 || ix >= G.nx) break; }
+                    else if (ey <= ez) { iy += sy; if (iy < 0 || iy >= G.ny) break; }
+                    else { iz += sz; if (iz < 0 || iz >= G.nz) break; }
+                }
+            }
+        }
+        const bool brute = active && !safe;
+        if (wave_any(brute)) {
+            float t2;
+            int i2;
+            closest_hit(r, brute, t_min, t_max, t2, i2, n_exact);
+            if (brute) {
+                closest = t2;
+                best = i2;
+            }
+        }
+        t_out = closest;
+        idx_out = best;
+    }
+};
+
+} // namespace rtk

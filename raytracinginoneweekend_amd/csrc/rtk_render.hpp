@@ -3,6 +3,7 @@
 #pragma once
 
 #include "rtk_device.hpp"
+#include "rtk_intersect.hpp"
 
 namespace rtk {
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "rtk_device.hpp"
+#include "rtk_intersect.hpp"
 #include "rtk_f16.hpp"
 
 #include "../../include/rtk.h"

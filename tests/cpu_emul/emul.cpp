@@ -3,6 +3,7 @@
 // TEST INFRASTRUCTURE ONLY — lets `pytest -m "not gpu"` check the kernels' logic against the oracle.
 // Build: g++ -std=c++17 -O2 -ffp-contract=off -mfma -DRTK_HOST_EMULATION -DRTK_LANES=1 -I. -I<csrc> ...
 #include "rtk_device.hpp"
+#include "rtk_intersect.hpp"
 #include "rtk_render.hpp"
 #include "rtk_scene_prep.hpp"
 
