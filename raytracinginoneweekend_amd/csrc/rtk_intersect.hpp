@@ -10,17 +10,17 @@ namespace rtk {
 
 // Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
 //
-// Stage 1 (filter, all spheres, pure VALU): a conservative sign test of a widened discriminant in
-// normalised-direction form, 11 VALU instructions per sphere, every lane of the wavefront testing the
-// same sphere (operands broadcast from LDS, or from scalar/global loads when !LDS).  The sign bits
-// are funnel-shifted into one mask word per 32 spheres.
+// Stage 1 (filter, all spheres, pure VALU): a conservative sign test — shipped: is the sphere's centre, projected on
+// the plane perpendicular to the ray, within r of the ray (9 VALU instructions per sphere; RTK_FILTER_FORM below) —
+// every lane of the wavefront testing the same sphere (operands broadcast from LDS, or from scalar/global loads when
+// !LDS).  The sign bits are funnel-shifted into one mask word per 32 spheres.
 // Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
 // Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
 #ifndef RTK_FILTER_FORM
 #define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test),
-                               // 2 (experiment build): packed-f16 projection form (5 / test) where the scene allows, else form 1
+                               // 2 (experiment build): packed-f16 projection form (5.25 / test) where the scene allows, else form 1
 #endif
 
 // RTK_SMEM=1 (experiment build, NOT the shipped default, never timed yet): the filter reads its sphere operands
@@ -66,7 +66,8 @@ constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 
 // Built on the host (rtk_scene_prep.hpp build_grid); opt-in (rtk_context_set_accel), for lists far beyond LDS size.
 // Every "gridable" sphere is registered in each cell its box overlaps, the box being inflated by everything the
 // reference's rounding could still accept for ray origins inside the ball (centre, r_allow); the few spheres that
-// are not gridable (non-finite, outliers such as the 1000-unit ground sphere) are tested for every ray.
+// are not gridable (outliers such as the 1000-unit ground sphere) are tested for every ray; a scene with a non-finite
+// sphere gets no grid at all (build_grid).
 struct GridDev {
     const uint32_t* cell_start;   // [zones][nx*ny*nz + 1]: one registration per zone of ray origins
     const uint32_t* items;        // sphere indices, ascending within a cell
