@@ -103,3 +103,98 @@ def test_two_rank_render_equals_single_rank(tmp_path):
         img = np.load(tmp_path / f"render{r}.npy")
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
         assert int(np.load(tmp_path / f"rays{r}.npy")[0]) == st["rays"]
+
+
+class _EmulContext:
+    """Stands in for rt.Context on the CPU: the entry points ShardedRenderer calls, taking the same raw pointers,
+    backed by the CPU build of the render kernel and numpy restatements of the small kernels."""
+
+    def __init__(self, scene):
+        import ctypes
+        from emul import Emul
+        self._e = Emul(scene)
+        self._ct = ctypes
+
+    def _view(self, ptr, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return np.frombuffer((self._ct.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
+
+    def set_stream(self, handle):
+        pass
+
+    def render_tiles_device(self, cam, params, ptr, want_stats=False):
+        tiles, st = self._e.render_tiles(cam, params, threads=2)
+        self._view(ptr, tiles.shape, np.float32)[...] = tiles
+        return st if want_stats else None
+
+    def quantise_device(self, src, n_pixels, spp, dst):
+        from oracle import pyoracle as po
+        self._view(dst, (n_pixels, 3), np.uint8)[...] = po.quantise(self._view(src, (n_pixels, 3), np.float32), spp)
+
+    def _deint(self, src, tprp, params, dst, dtype):
+        world = max(1, params.world_size)
+        g = self._view(src, (world, tprp, 64, 3), dtype)
+        self._view(dst, (params.height, params.width, 3), dtype)[...] = deinterleave(g, params.width, params.height, world)
+
+    def deinterleave_device(self, src, tprp, params, dst):
+        self._deint(src, tprp, params, dst, np.float32)
+
+    def deinterleave_u8_device(self, src, tprp, params, dst):
+        self._deint(src, tprp, params, dst, np.uint8)
+
+
+class _NoStream:
+    cuda_stream = 1
+
+    def wait_stream(self, other): pass
+    def wait_event(self, ev): pass
+    def synchronize(self): pass
+
+
+class _NoEvent:
+    def record(self, stream): pass
+
+
+def _sharded_worker(rank, world, W, H, port, out_dir):
+    import contextlib
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raytracinginoneweekend_amd as rt
+    from raytracinginoneweekend_amd import distributed as rd
+    torch.cuda.Stream = lambda device=None: _NoStream()
+    torch.cuda.current_stream = lambda device=None: _NoStream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.Event = _NoEvent
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = rt.stock_scene()
+    cam = rt.stock_camera(W / H)
+    sr = rd.ShardedRenderer(_EmulContext(scene), W, H, rank, world, torch.device("cpu"), extra_contexts=[_EmulContext(scene)])
+    frames = []
+    for i in range(3):                                   # contexts alternate: 0, 1, 0
+        sr.render(cam, 2, 10, seed=10 + i)
+        frames.append(sr.image.numpy().copy())
+    sr.render(cam, 2, 10, seed=10, output="u8")
+    np.save(os.path.join(out_dir, f"sh{rank}.npy"), np.stack(frames))
+    np.save(os.path.join(out_dir, f"sh8_{rank}.npy"), sr.image_u8.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_renderer_itself_on_two_gloo_ranks(tmp_path):
+    """The real ShardedRenderer (two contexts alternating, f32 and u8 output) over gloo, its context replaced by the CPU
+    build of the kernel: every rank ends up with the single-rank image, frame after frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raytracinginoneweekend_amd as rt
+    from emul import Emul
+    from oracle import pyoracle as po
+    world, W, H = 2, 37, 23
+    port = 29000 + (os.getpid() * 13 + 1234) % 2000
+    mp.spawn(_sharded_worker, args=(world, W, H, port, str(tmp_path)), nprocs=world, join=True)
+    e = Emul(rt.stock_scene())
+    refs = [e.render(rt.stock_camera(W / H), W, H, 2, 10, seed=10 + i, threads=2)[0] for i in range(3)]
+    for r in range(world):
+        got = np.load(tmp_path / f"sh{r}.npy")
+        for i in range(3):
+            assert np.array_equal(got[i].view(np.uint32), refs[i].view(np.uint32)), (r, i)
+        assert np.array_equal(np.load(tmp_path / f"sh8_{r}.npy"), po.quantise(refs[0], 2))
