@@ -5,6 +5,7 @@
 # Build everything on the CPU first: python -m raytracinginoneweekend_amd.build && python tools/build_variants.py &&
 #   hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/bin/valu_rates
 # Stages:
+#   smoke    __graft_entry__.smoke(): one small invocation against the oracle     -> gpurun_out/<tag>_smoke.log
 #   verify   GPU tests, then the headline bench line                       -> gpurun_out/<tag>_tests.log, <tag>_bench.json
 #   rates    issue rates of candidate filter instructions                  -> gpurun_out/<tag>_valu_rates.txt
 #   ab       interleaved A/B of the kernel variants at 100 spp             -> gpurun_out/<tag>_ab.txt
@@ -26,6 +27,8 @@ step() {   # step <seconds> <log> <command...>
     tail -3 "$log"
 }
 case "$STAGE" in
+  smoke)     # the smallest possible first contact with the GPU: one intersect batch and one small frame against the oracle
+    step 300 gpurun_out/${TAG}_smoke.log python -c "import __graft_entry__ as g; g.smoke()" ;;
   verify)
     step 900 gpurun_out/${TAG}_tests.log python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread
     step 400 gpurun_out/${TAG}_bench.json python bench.py ;;
