@@ -141,7 +141,7 @@ struct Intersector {
 #define RTK_ALWAYS_LOAD(w) (reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(always))[w])
 #endif
 #ifndef RTK_PAIR_GROUP
-#define RTK_PAIR_GROUP 2
+#define RTK_PAIR_GROUP (RTK_SMEM ? 4 : 2)      // scalar loads fetch four pair records (s_load_dwordx16) at a time
 #endif
     static constexpr int kPairGroup = RTK_PAIR_GROUP;     // pairs processed together (2 or 4; more = more registers)
     // Packed-f16 form: TWO spheres per register (one in each half), 10 instructions per pair = 5 per test:
@@ -286,11 +286,35 @@ struct Intersector {
                     list_base = base + w * 32;
                 }
                 uint32_t m = 0;
+#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
+                // Scalar loads return out of order, so a wait for one is a wait for all (lgkmcnt(0)): the next group of four
+                // spheres (one s_load_dwordx16) is requested right AFTER the wait for the current one — which the first
+                // sphere's arithmetic forces — and stays in flight behind the other three.
+                typedef decltype(load(0)) Rec;
+                Rec q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = load(w * 32 + j);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    filter_one(f, q[0].x, q[0].y, q[0].z, q[0].w, m);
+                    RTK_SCHED_BARRIER();
+                    const int nx = w * 32 + 4 * (g < 7 ? g + 1 : g);      // last group: re-reads itself, never beyond the word
+                    Rec nq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nq[j] = load(nx + j);
+                    RTK_SCHED_BARRIER();
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) filter_one(f, q[j].x, q[j].y, q[j].z, q[j].w, m);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = nq[j];
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const auto s = load(w * 32 + i);
                     filter_one(f, s.x, s.y, s.z, s.w, m);
                 }
+#endif
                 RTK_STAT(lane, filter_words);
                 emit(base + w * 32, to_cand(m, 0xFFFFFFFFu));
             }
@@ -331,14 +355,27 @@ struct Intersector {
                     // last group: re-reads itself, never beyond the word
                     const int nx = w * 16 + kPairGroup * (g + 1 < 16 / kPairGroup ? g + 1 : g);
                     Rec nq[kPairGroup];
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
-                    RTK_SCHED_BARRIER();      // keep these requests ahead of the arithmetic on the previous group
                     H2 x[kPairGroup], y[kPairGroup];
+#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
+                    // scalar loads: a wait for one is a wait for all, so the next group is requested right after the
+                    // wait for this one (forced by the first stage) and stays in flight behind the other stages
 #pragma unroll
                     for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
 #pragma unroll
                     for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
+                    RTK_SCHED_BARRIER();
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
+                    RTK_SCHED_BARRIER();
+#else
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
+                    RTK_SCHED_BARRIER();      // LDS reads return in order: keep these requests ahead of the arithmetic on the previous group
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
+#pragma unroll
+                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
+#endif
 #pragma unroll
                     for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].y), f.b1, x[j]);
 #pragma unroll
