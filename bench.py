@@ -16,7 +16,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
   roofline     : the render kernel against the FP32 vector peak, algorithmic flops = 17 per ray-sphere
                  test x 484 spheres per ray, kernel time from HIP events on the kernel's stream
   cpu_baseline : the reference compiled unmodified (oracle/_ref/rtiow_ref, kind "reference") or, if that
-                 binary is absent, the oracle restatement (kind "port"), one thread, on a bounded sample.
+                 binary is absent, the oracle restatement (kind "port"), one thread, on a bounded sample (~10 s).
 """
 from __future__ import annotations
 
@@ -54,7 +54,7 @@ def cpu_baseline():
         if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
             # the reference executable renders whole images only: same scene, camera aspect (3:2) and depth,
             # reduced resolution and spp; its own ProfileLogScope times the "Image Generation" scope (main.cpp:63)
-            argv = ["300", "200", "6", str(DEPTH)]
+            argv = ["300", "200", "12", str(DEPTH)]        # ~10 s of single-thread CPU work
             with tempfile.TemporaryDirectory() as td:
                 r = subprocess.run([ref_bin, *argv], cwd=td, capture_output=True, text=True, timeout=600)
             m = re.search(r"Image Generation took ([0-9.eE+-]+) seconds", r.stderr)
@@ -62,11 +62,11 @@ def cpu_baseline():
             # rays of that exact run: the oracle renders the bit-identical image (golden hashes), so its count is the reference's
             o = po.Oracle()
             o.random_scene()
-            _, _, seg = o.render_rows(po.stock_camera(1.5), 300, 200, 6, DEPTH, want_u8=False)
+            _, _, seg = o.render_rows(po.stock_camera(1.5), 300, 200, 12, DEPTH, want_u8=False)
             return {"value": seg / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
-                    "sample": "reference executable (g++ -O2 -ffp-contract=off, unmodified sources), stock scene, 300x200, 6 spp, depth 50: "
+                    "sample": "reference executable (g++ -O2 -ffp-contract=off, unmodified sources), stock scene, 300x200, 12 spp, depth 50: "
                               "%d rays in %.2f s (its own 'Image Generation' scope)" % (seg, secs),
-                    "samples_per_s": 300 * 200 * 6 / secs}
+                    "samples_per_s": 300 * 200 * 12 / secs}
     except Exception as e:   # fall through to the port
         print("cpu_baseline: reference binary failed (%s); timing the oracle port instead" % e, file=sys.stderr)
     o = po.Oracle()
