@@ -79,8 +79,11 @@ static size_t lds_bytes(bool lds, int npad) {
 template <bool LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);
-    render_wave<LDS, GRID>(A, isect);
+    __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
+    if (threadIdx.x < sizeof(CameraDev) / sizeof(float))
+        reinterpret_cast<float*>(&s_cam)[threadIdx.x] = reinterpret_cast<const float*>(&A.cam)[threadIdx.x];
+    const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);      // ends with __syncthreads()
+    render_wave<LDS, GRID>(A, isect, &s_cam);
 }
 
 // accumulators -> fp32 sums, and clear them for the next frame.

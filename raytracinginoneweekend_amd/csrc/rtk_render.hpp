@@ -54,8 +54,11 @@ __device__ __forceinline__ unsigned long long to_fixed_32_32(float f) {
     return (static_cast<unsigned long long>(top) << 32) | lo;
 }
 
+// `cam`: where the camera is read from in the primary-ray block.  The kernel hands in an LDS copy: the 22 floats are
+// needed once per pass, and as kernel arguments they sit in SGPRs that the register allocator spills to VGPR lanes
+// and reads back with v_readlane (VALU slots) in every pass; from LDS they cost six reads on the LDS pipe instead.
 template <bool LDS, bool GRID = false>
-__device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect) {
+__device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect, const CameraDev* cam) {
     const int lane = isect.lane;
     const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
 
@@ -153,7 +156,8 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         if (start) {
             const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
             const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
-            ray = primary_ray(A.cam, px, prow, A.W, A.H, u);
+            asm volatile("" ::: "memory");      // keep the camera reads in this block (hoisted, they would occupy 22 VGPRs for the whole loop)
+            ray = primary_ray(*cam, px, prow, A.W, A.H, u);
             thr = {1.0f, 1.0f, 1.0f};
             depth_left = A.max_depth;
             bounce = 0;

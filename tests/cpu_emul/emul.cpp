@@ -220,8 +220,8 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
             std::vector<float4> stage(kStageSpheres);
             run_lanes([&](int lane) {
                 const Intersector<false> it = make_isect(e, list.data(), nullptr, lane, RTK_STAGED_LARGE ? stage.data() : nullptr);
-                if (accel) render_wave<false, true>(A, it);
-                else render_wave<false, false>(A, it);
+                if (accel) render_wave<false, true>(A, it, &A.cam);
+                else render_wave<false, false>(A, it, &A.cam);
             });
             fold_stats();
         });
