@@ -66,6 +66,11 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 #endif
     it.n = sc.n;
     it.fb = sc.fb;
+#if RTK_FILTER_FORM == 2
+    __shared__ FilterBounds s_fb;
+    if (threadIdx.x < sizeof(FilterBounds) / 4) reinterpret_cast<uint32_t*>(&s_fb)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&sc.fb)[threadIdx.x];
+    it.fb_mem = &s_fb;      // visible after the __syncthreads() below
+#endif
     it.lane = lane;
     __syncthreads();
     return it;

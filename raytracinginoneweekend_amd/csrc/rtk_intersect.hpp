@@ -94,6 +94,7 @@ struct Intersector {
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
     float4* stage = nullptr;     // RTK_STAGED_LARGE: this wave's LDS chunk of kStageSpheres filter operands
     FilterBounds fb;
+    const FilterBounds* fb_mem = nullptr;   // RTK_FILTER_FORM == 2: an LDS copy of `fb`, read once per ray (keeps ~16 words out of SGPRs)
     int n;
     int lane;
 #ifdef RTK_HOST_EMULATION
@@ -199,6 +200,8 @@ struct Intersector {
         const float u2x = bb, u2y = fmaf(dy, dy * aa, sg), u2z = -dy;
 #if RTK_FILTER_FORM == 2
         if (fb.f16_ok) {
+            asm volatile("" ::: "memory");      // the reads of *fb_mem stay here (hoisted, they would be spilled SGPRs again)
+            const FilterBounds& fb = *fb_mem;   // shadows the by-value member inside this block
             // Filter space: recentred and scaled by a power of two (binary16 has 5 exponent bits).
             const float ox = (r.o.x - fb.cen[0]) * fb.scale, oy = (r.o.y - fb.cen[1]) * fb.scale, oz = (r.o.z - fb.cen[2]) * fb.scale;
             const float o_len = __builtin_amdgcn_sqrtf(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));

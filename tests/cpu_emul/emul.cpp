@@ -60,6 +60,7 @@ static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg
     it.always = e.ps.always_mask.empty() ? nullptr : e.ps.always_mask.data();
     it.list = list;
     it.fb = e.ps.fb;
+    it.fb_mem = &e.ps.fb;
     it.n = e.ps.n;
     it.lane = lane;
     it.stage = stage;
