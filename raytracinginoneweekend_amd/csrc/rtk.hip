@@ -81,8 +81,15 @@ static size_t lds_bytes(bool lds, int npad) {
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
+// RTK_WAVES_PER_EU=n (experiment builds): ask the register allocator for a budget that lets n waves share a SIMD
+// (512 / n registers per lane, in steps of 8).
+#ifdef RTK_WAVES_PER_EU
+#define RTK_OCCUPANCY_HINT __attribute__((amdgpu_waves_per_eu(RTK_WAVES_PER_EU, RTK_WAVES_PER_EU)))
+#else
+#define RTK_OCCUPANCY_HINT
+#endif
 template <bool LDS, bool GRID = false>
-__global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
+__global__ __launch_bounds__(kBlockThreads) RTK_OCCUPANCY_HINT void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
     if (threadIdx.x < sizeof(CameraDev) / sizeof(float))

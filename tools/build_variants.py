@@ -18,6 +18,7 @@ VARIANTS = {
     "f16smem": ["-DRTK_FILTER_FORM=2", "-DRTK_SMEM=1"],   # both: pair records by s_load_dwordx16 (8 spheres per load), v_pk_fma_f16 with SGPR sources, no LDS in the loop
     "f16smem_exactg": ["-DRTK_FILTER_FORM=2", "-DRTK_SMEM=1", "-DRTK_EXACT_GLOBAL=1"],   # ... and no scene data in LDS at all (8 KiB of candidate lists per workgroup)
     "exactg": ["-DRTK_EXACT_GLOBAL=1"],            # exact-stage operands from global memory: 16 instead of 24 KiB LDS per workgroup (7 waves/SIMD)
+    "exactg7": ["-DRTK_EXACT_GLOBAL=1", "-DRTK_WAVES_PER_EU=7"],   # ... with the register budget of 7 waves per SIMD (71 VGPRs, no spills)
     "staged": ["-DRTK_STAGED_LARGE=1"],            # scenes > 1024 spheres: stream the list through wave-private LDS chunks (only differs for such scenes)
 }
 os.makedirs(OUT, exist_ok=True)
