@@ -22,74 +22,42 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists.
-// RTK_EXACT_GLOBAL=1 (experiment build): the exact stage's operands stay in global memory (an 8 KiB table, L1-resident;
-// the loads are per-lane gathers either way), which takes the workgroup from 24 to 16 KiB of LDS: 7 waves per SIMD
-// (register-limited) instead of 6.
-#ifndef RTK_EXACT_GLOBAL
-#define RTK_EXACT_GLOBAL 0
-#endif
-// (RTK_SMEM builds read the filter operands by scalar loads from global memory: no LDS copy of them either.)
-constexpr int kLdsBytesPerSphere = (RTK_SMEM ? 0 : 16) + (RTK_EXACT_GLOBAL ? 0 : 16);
+// Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists |
+// (!LDS only) [4][kStageSpheres] float4 staging chunks, one per wave.
+constexpr int kLdsBytesPerSphere = 32;
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
-    it.filt_global = sc.filt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {
-        float4* cursor = reinterpret_cast<float4*>(p);
-#if RTK_SMEM
-        it.filt = sc.filt;
-#else
-        float4* lf = cursor;
-        cursor += sc.npad;
+        float4* lf = reinterpret_cast<float4*>(p);
+        float4* le = lf + sc.npad;
         for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) lf[i] = sc.filt[i];
-        it.filt = lf;
-#endif
-#if RTK_EXACT_GLOBAL
-        it.exact = sc.exact;
-#else
-        float4* le = cursor;
         for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) le[i] = sc.exact[i];
+        it.filt = lf;
         it.exact = le;
-#endif
         p += static_cast<size_t>(sc.npad) * kLdsBytesPerSphere;
     } else {
         it.filt = sc.filt;
         it.exact = sc.exact;
     }
-    it.always = sc.always_mask;
     it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
-#if RTK_STAGED_LARGE
     if (!LDS) it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
-#endif
     it.n = sc.n;
     it.fb = sc.fb;
-#if RTK_FILTER_FORM == 2
-    __shared__ FilterBounds s_fb;
-    if (threadIdx.x < sizeof(FilterBounds) / 4) reinterpret_cast<uint32_t*>(&s_fb)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&sc.fb)[threadIdx.x];
-    it.fb_mem = &s_fb;      // visible after the __syncthreads() below
-#endif
     it.lane = lane;
     __syncthreads();
     return it;
 }
 
 static size_t lds_bytes(bool lds, int npad) {
-    return (lds ? static_cast<size_t>(npad) * kLdsBytesPerSphere : (RTK_STAGED_LARGE ? kWavesPerBlock * kStageSpheres * sizeof(float4) : 0)) + kWavesPerBlock * kListCap * kWave * 2;
+    return (lds ? static_cast<size_t>(npad) * kLdsBytesPerSphere : kWavesPerBlock * kStageSpheres * sizeof(float4)) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
-// RTK_WAVES_PER_EU=n (experiment builds): ask the register allocator for a budget that lets n waves share a SIMD
-// (512 / n registers per lane, in steps of 8).
-#ifdef RTK_WAVES_PER_EU
-#define RTK_OCCUPANCY_HINT __attribute__((amdgpu_waves_per_eu(RTK_WAVES_PER_EU, RTK_WAVES_PER_EU)))
-#else
-#define RTK_OCCUPANCY_HINT
-#endif
 template <bool LDS, bool GRID = false>
-__global__ __launch_bounds__(kBlockThreads) RTK_OCCUPANCY_HINT void render_kernel(const RenderArgs A) {
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
     if (threadIdx.x < sizeof(CameraDev) / sizeof(float))
@@ -245,7 +213,6 @@ struct rtk_context {
     SceneDev scene = {};
     bool have_scene = false;
     DevBuf filt, exact, mat0, mat1;
-    DevBuf amask;        // RTK_FILTER_FORM == 2: per-word masks of the spheres the filter must always pass
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
     std::vector<uint2> runs_host;
     int runs_key[4] = {-1, -1, -1, -1};
@@ -353,7 +320,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->amask, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -400,14 +367,6 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     HIP_TRY(hipMemcpy(c->mat1.p, m1.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
                 static_cast<const float4*>(c->mat1.p), n, npad, fb};
-#if RTK_FILTER_FORM == 2
-    if (fb.f16_ok) {
-        if (ps.always_mask.size() != static_cast<size_t>(npad / 32)) return fail(RTK_ERR_HIP, "internal: always-mask size");
-        HIP_TRY(c->amask.reserve(ps.always_mask.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(c->amask.p, ps.always_mask.data(), ps.always_mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->scene.always_mask = static_cast<const uint32_t*>(c->amask.p);
-    }
-#endif
     c->have_scene = true;
     c->h_cx.assign(s->cx, s->cx + n); c->h_cy.assign(s->cy, s->cy + n); c->h_cz.assign(s->cz, s->cz + n); c->h_radius.assign(s->radius, s->radius + n);
     c->grid_ok = false;

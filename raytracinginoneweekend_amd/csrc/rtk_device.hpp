@@ -36,12 +36,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kListCap = 16;         // per-lane candidate list entries between flushes
 constexpr int kMaxLdsSpheres = 1024; // scenes up to this size are LDS-resident (32 B per sphere)
 
-// Relative widening of the filter: the filter accepts when hb^2 (1+k) + r^2 (1+k) >= |oc|^2 with
-// (1+k) = (1+2^-15)^2; the reference's own rounding error in its discriminant is < 2^-19 relative
-// to (|oc|^2 + r^2), so every sphere whose reference discriminant is >= 0 is
-// a candidate.
-constexpr float kFilterScale = 1.0f + 0x1p-15f;                          // applied to d-hat
-constexpr float kFilterScaleSq = (1.0f + 0x1p-15f) * (1.0f + 0x1p-15f);  // applied to r^2 (host)
+// Relative widening of the filter's radius term: r^2 (1+2^-15)^2 (host, rtk_scene_prep.hpp); it absorbs the rounding of
+// the squares and sums of the projected distances.
+constexpr float kFilterScaleSq = (1.0f + 0x1p-15f) * (1.0f + 0x1p-15f);
 
 struct V3 {
     float x, y, z;
@@ -116,27 +113,7 @@ struct FilterBounds {
     float c_max;     // max |C| + |r|
     float r_max2;    // max r^2
     float r_min;     // min |r|
-    // RTK_FILTER_FORM == 2 (packed-f16 projection filter).  Filter space = (x - cen) * scale, scale a power of two
-    // that puts the scene's reach into [2^7, 2^8).  f16_ok == 0: this scene's `filt` holds the f32 records of form 1.
-    int32_t f16_ok;
-    float cen[3];
-    float scale;
-    int32_t ax[3];       // coordinate order of the f16 chain: ax[0] (largest extent) first ... ax[2] (smallest) last
-    float cmax_s[3];     // per chain position: max |c_hat| over the filterable spheres, filter space
-    float c_max_s;       // max |C'| + |r|, filter space
-    float r_min_s;       // min |r|, filter space
-    float r_max2_s;      // max r^2, filter space
 };
-
-// Packed binary16 pairs for the form-2 filter.  (The CPU build models them in tests/cpu_emul/rtk_host_shim.hpp.)
-#ifndef RTK_HOST_EMULATION
-typedef _Float16 H2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ H2 h2_splat(float v) { const _Float16 h = static_cast<_Float16>(v); return H2{h, h}; }   // v_cvt_f16_f32: nearest even
-__device__ __forceinline__ H2 h2_from_bits(float bits) { return __builtin_bit_cast(H2, bits); }
-__device__ __forceinline__ uint32_t h2_bits(H2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ float h2_lo(H2 v) { return static_cast<float>(v.x); }
-__device__ __forceinline__ H2 h2_fma(H2 a, H2 b, H2 c) { return __builtin_elementwise_fma(a, b, c); }                // v_pk_fma_f16
-#endif
 
 struct SceneDev {
     const float4* filt;   // [npad] cx, cy, cz, r^2 (1+k): filter operands; pads never pass
@@ -146,7 +123,6 @@ struct SceneDev {
     int32_t n;
     int32_t npad;         // n rounded up to a multiple of 32
     FilterBounds fb;
-    const uint32_t* always_mask = nullptr;   // RTK_FILTER_FORM == 2: [npad / 32] per word, MSB = first sphere: spheres the filter must pass
 };
 
 struct CameraDev {

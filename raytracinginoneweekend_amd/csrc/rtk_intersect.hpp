@@ -10,34 +10,14 @@ namespace rtk {
 
 // Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
 //
-// Stage 1 (filter, all spheres, pure VALU): a conservative sign test — shipped: is the sphere's centre, projected on
-// the plane perpendicular to the ray, within r of the ray (9 VALU instructions per sphere; RTK_FILTER_FORM below) —
-// every lane of the wavefront testing the same sphere (operands broadcast from LDS, or from scalar/global loads when
-// !LDS).  The sign bits are funnel-shifted into one mask word per 32 spheres.
+// Stage 1 (filter, all spheres, pure VALU): a conservative sign test — is the sphere's centre, projected on the plane
+// perpendicular to the ray, within r of the ray (9 VALU instructions per sphere) — every lane of the wavefront testing
+// the same sphere (operands broadcast from LDS; scenes too large for LDS stream through a wave-private LDS chunk).
+// The sign bits are funnel-shifted into one mask word per 32 spheres.
 // Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
 // Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
-#ifndef RTK_FILTER_FORM
-#define RTK_FILTER_FORM 1      // 0: discriminant form (11 VALU / test), 1: projection form (9 VALU / test),
-                               // 2 (experiment build): packed-f16 projection form (5.25 / test) where the scene allows, else form 1
-#endif
-
-// RTK_SMEM=1 (experiment build, NOT the shipped default, never timed yet): the filter reads its sphere operands
-// with scalar loads from the GLOBAL copy of `filt` through the constant address space, so they arrive as SGPR
-// operands: no LDS traffic and no broadcast VGPR writes.  The pointer cast is only ever applied to `filt_global`
-// (device global memory, read-only for the kernel's lifetime) — never to an LDS address.
-#ifndef RTK_SMEM
-#define RTK_SMEM 0
-#endif
-#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
-typedef float rtk_f4v __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
-#define RTK_FILT_LOAD(i) (reinterpret_cast<rtk_const_f4_ptr>(reinterpret_cast<uintptr_t>(filt_global))[i])
-#else
-#define RTK_FILT_LOAD(i) (filt[i])
-#endif
-
 // Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
 #ifdef RTK_HOST_EMULATION
 #define RTK_SCHED_BARRIER() ((void)0)
@@ -45,11 +25,9 @@ typedef const __attribute__((address_space(4))) rtk_f4v* rtk_const_f4_ptr;
 #define RTK_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-// RTK_STAGED_LARGE=1 (experiment build, default off until it has run on a GPU): scenes beyond kMaxLdsSpheres stream
-// the sphere list through a wave-private LDS chunk instead of reading every sphere with a broadcast global load.
-#ifndef RTK_STAGED_LARGE
-#define RTK_STAGED_LARGE 0
-#endif
+// Scenes beyond kMaxLdsSpheres stream the sphere list through a wave-private LDS chunk (one coalesced global load per
+// 64 spheres) instead of reading every sphere with a broadcast global load (measured on the 10k-sphere scene of
+// BASELINE.json configs[3]: 1.56x the broadcast-load walk, profiles/r02_config4.md).
 constexpr int kStageSpheres = 128;   // spheres per staged chunk (a multiple of 32)
 #ifdef RTK_HOST_EMULATION
 #define RTK_WAVE_SYNC() ((void)__ballot(true))      // the fibers of a wave are not in lockstep between votes
@@ -88,13 +66,10 @@ struct GridDev {
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
-    const float4* filt_global;   // always the global-memory copy (RTK_SMEM reads through it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
-    const uint32_t* always = nullptr;   // RTK_FILTER_FORM == 2: SceneDev::always_mask (global; read with wave-uniform indices)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
-    float4* stage = nullptr;     // RTK_STAGED_LARGE: this wave's LDS chunk of kStageSpheres filter operands
+    float4* stage = nullptr;     // !LDS: this wave's LDS chunk of kStageSpheres filter operands
     FilterBounds fb;
-    const FilterBounds* fb_mem = nullptr;   // RTK_FILTER_FORM == 2: an LDS copy of `fb`, read once per ray (keeps ~16 words out of SGPRs)
     int n;
     int lane;
 #ifdef RTK_HOST_EMULATION
@@ -120,57 +95,17 @@ struct Intersector {
         cnt = 0;
     }
 
-    // Per-ray operands of the filter.
+    // Per-ray operands of the filter: the shrunk basis (e1, e2) of the plane perpendicular to the ray and -o.e.
     struct FilterRay {
-#if RTK_FILTER_FORM == 0
-        float ox, oy, oz, dhx, dhy, dhz;
-#else
         float e1x, e1y, e1z, ns1, e2x, e2y, e2z, ns2;
-#endif
-#if RTK_FILTER_FORM == 2
-        H2 a1, b1, c1, n1, a2, b2, c2, n2;     // e1 / e2 components in chain order and -o.e, shrunk by g, each in both halves
-#endif
     };
 
-#if RTK_FILTER_FORM == 2
-    // `always` is SceneDev::always_mask: device GLOBAL memory, read-only while a kernel runs, indexed by a wave-uniform
-    // word number — read with a scalar load (constant address space) so it costs no vector register.  (Never apply
-    // this cast to an LDS pointer.)
-#ifdef RTK_HOST_EMULATION
-#define RTK_ALWAYS_LOAD(w) (always[w])
-#else
-#define RTK_ALWAYS_LOAD(w) (reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(always))[w])
-#endif
-#ifndef RTK_PAIR_GROUP
-#define RTK_PAIR_GROUP (RTK_SMEM ? 4 : 2)      // scalar loads fetch four pair records (s_load_dwordx16) at a time
-#endif
-    static constexpr int kPairGroup = RTK_PAIR_GROUP;     // pairs processed together (2 or 4; more = more registers)
-    // Packed-f16 form: TWO spheres per register (one in each half), 10 instructions per pair = 5 per test:
-    // 2 x 3 v_pk_fma_f16 for the two projections, 2 v_pk_fma_f16 for p1^2 + p2^2 - rho^2, then the two sign bits
-    // (bits 31 and 15) are rotated to their place in the word's mask and merged (v_alignbit_b32, v_and_or_b32).
-    // rec = (c_hat[ax0], c_hat[ax1], c_hat[ax2], -rho^2), each dword holding the value for both spheres of the pair.
-    static __device__ __forceinline__ uint32_t filter_pair_f16(const FilterRay& f, float rx, float ry, float rz, float rw) {
-        const H2 ca = h2_from_bits(rx), cb = h2_from_bits(ry), cc = h2_from_bits(rz), k = h2_from_bits(rw);
-        const H2 p1 = h2_fma(cc, f.c1, h2_fma(cb, f.b1, h2_fma(ca, f.a1, f.n1)));
-        const H2 p2 = h2_fma(cc, f.c2, h2_fma(cb, f.b2, h2_fma(ca, f.a2, f.n2)));
-        return h2_bits(h2_fma(p2, p2, h2_fma(p1, p1, k)));
-    }
-#endif
-
-    // One ray-sphere filter test; shifts the result bit into `m` (form 0: 1 = certainly missed, form 1: 1 = candidate).
+    // One ray-sphere filter test; shifts the result bit into `m` (1 = candidate).
     static __device__ __forceinline__ void filter_one(const FilterRay& f, float sx, float sy, float sz, float sw, uint32_t& m) {
-#if RTK_FILTER_FORM == 0
-        const float x = f.ox - sx, y = f.oy - sy, z = f.oz - sz;
-        const float hb = fmaf(z, f.dhz, fmaf(y, f.dhy, x * f.dhx));
-        const float c = fmaf(z, z, fmaf(y, y, fmaf(x, x, -sw)));
-        const float disc = fmaf(hb, hb, -c);
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(disc), 31);
-#else
         const float p1 = fmaf(sz, f.e1z, fmaf(sy, f.e1y, fmaf(sx, f.e1x, f.ns1)));
         const float p2 = fmaf(sz, f.e2z, fmaf(sy, f.e2y, fmaf(sx, f.e2x, f.ns2)));
         const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
         m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
-#endif
     }
 
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
@@ -180,14 +115,9 @@ struct Intersector {
         // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
         // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
         const float big = 0x1p30f;
-        bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
         FilterRay f;
         const float inv_len = __builtin_amdgcn_rsqf(a);
-#if RTK_FILTER_FORM == 0
-        // d-hat widened by (1+2^-15).  v_rsq_f32 is 1 ulp; its error is far inside the margin.
-        f.ox = r.o.x; f.oy = r.o.y; f.oz = r.o.z;
-        f.dhx = r.d.x * (inv_len * kFilterScale); f.dhy = r.d.y * (inv_len * kFilterScale); f.dhz = r.d.z * (inv_len * kFilterScale);
-#else
         // Orthonormal basis (e1, e2) of the plane perpendicular to the ray (Duff et al. 2017, branch-free);
         // a sphere can only be hit if its centre, projected on that plane, lies within r of the ray.
         // The projected distances are shrunk by g < 1 so that everything the reference's own rounding could
@@ -198,38 +128,6 @@ struct Intersector {
         const float bb = dx * dy * aa;
         const float u1x = fmaf(sg * dx, dx * aa, 1.0f), u1y = sg * bb, u1z = -sg * dx;     // unshrunk basis
         const float u2x = bb, u2y = fmaf(dy, dy * aa, sg), u2z = -dy;
-#if RTK_FILTER_FORM == 2
-        if (fb.f16_ok) {
-            asm volatile("" ::: "memory");      // the reads of *fb_mem stay here (hoisted, they would be spilled SGPRs again)
-            const FilterBounds& fb = *fb_mem;   // shadows the by-value member inside this block
-            // Filter space: recentred and scaled by a power of two (binary16 has 5 exponent bits).
-            const float ox = (r.o.x - fb.cen[0]) * fb.scale, oy = (r.o.y - fb.cen[1]) * fb.scale, oz = (r.o.z - fb.cen[2]) * fb.scale;
-            const float o_len = __builtin_amdgcn_sqrtf(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));
-            const float M = o_len + fb.c_max_s;
-            const float E = 0x1p-19f * fmaf(M, M, fb.r_max2_s);
-            const float dp = 0x1p-19f * M;
-            // coordinates in chain order (a scene-wide permutation: largest extent first, smallest last)
-            auto pick = [](float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); };
-            const float a1 = pick(u1x, u1y, u1z, fb.ax[0]), b1 = pick(u1x, u1y, u1z, fb.ax[1]), c1 = pick(u1x, u1y, u1z, fb.ax[2]);
-            const float a2 = pick(u2x, u2y, u2z, fb.ax[0]), b2 = pick(u2x, u2y, u2z, fb.ax[1]), c2 = pick(u2x, u2y, u2z, fb.ax[2]);
-            const float oa = pick(ox, oy, oz, fb.ax[0]), ob = pick(ox, oy, oz, fb.ax[1]), oc = pick(ox, oy, oz, fb.ax[2]);
-            // binary16 error of one projected coordinate of a sphere that matters (|p| <= r~), per unit of g
-            // (DESIGN.md §4.1 form 2): basis quantisation u M, rounding of -o.e, and the three chain roundings
-            // u (3|p| + 2|t_last| + |t_mid|); the 3|p| part, subnormal steps and the roundings of p^2 - rho^2 are
-            // inside the per-sphere rho.
-            const float n1 = fabsf(fmaf(oc, c1, fmaf(ob, b1, oa * a1))), n2 = fabsf(fmaf(oc, c2, fmaf(ob, b2, oa * a2)));
-            const float k1 = n1 + fmaf(2.0f * fb.cmax_s[2], fabsf(c1), fb.cmax_s[1] * fabsf(b1));
-            const float k2 = n2 + fmaf(2.0f * fb.cmax_s[2], fabsf(c2), fb.cmax_s[1] * fabsf(b2));
-            const float d16 = (1.03f * 0x1p-11f) * (M + fmaxf(k1, k2));
-            const float g = fb.r_min_s * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min_s, fb.r_min_s, E)) + 2.0f * (dp + d16)) * (1.0f - 0x1p-16f);
-            safe = safe && (o_len < 0x1p15f) && (g > 0x1p-6f);      // |o.e| stays below binary16's 65504; below that g the margins stop scaling with g
-            f.a1 = h2_splat(g * a1); f.b1 = h2_splat(g * b1); f.c1 = h2_splat(g * c1);
-            f.a2 = h2_splat(g * a2); f.b2 = h2_splat(g * b2); f.c2 = h2_splat(g * c2);
-            // -o.e against the QUANTISED basis, so that only its own rounding to binary16 remains
-            f.n1 = h2_splat(-fmaf(oc, h2_lo(f.c1), fmaf(ob, h2_lo(f.b1), oa * h2_lo(f.a1))));
-            f.n2 = h2_splat(-fmaf(oc, h2_lo(f.c2), fmaf(ob, h2_lo(f.b2), oa * h2_lo(f.a2))));
-        } else
-#endif
         {
             const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
             const float M = o_len + fb.c_max;
@@ -241,7 +139,6 @@ struct Intersector {
             f.ns1 = -fmaf(r.o.z, f.e1z, fmaf(r.o.y, f.e1y, r.o.x * f.e1x));
             f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
         }
-#endif
         RTK_STAT(lane, closest_hit_calls);
         float closest = t_max;
         int best = -1;
@@ -272,9 +169,6 @@ struct Intersector {
             }
         };
         auto to_cand = [&](uint32_t m, uint32_t valid) -> uint32_t {
-#if RTK_FILTER_FORM == 0
-            m = ~m;
-#endif
             uint32_t cand = (safe ? m : 0xFFFFFFFFu) & valid;
             return active ? cand : 0u;
         };
@@ -289,35 +183,11 @@ struct Intersector {
                     list_base = base + w * 32;
                 }
                 uint32_t m = 0;
-#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
-                // Scalar loads return out of order, so a wait for one is a wait for all (lgkmcnt(0)): the next group of four
-                // spheres (one s_load_dwordx16) is requested right AFTER the wait for the current one — which the first
-                // sphere's arithmetic forces — and stays in flight behind the other three.
-                typedef decltype(load(0)) Rec;
-                Rec q[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = load(w * 32 + j);
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    filter_one(f, q[0].x, q[0].y, q[0].z, q[0].w, m);
-                    RTK_SCHED_BARRIER();
-                    const int nx = w * 32 + 4 * (g < 7 ? g + 1 : g);      // last group: re-reads itself, never beyond the word
-                    Rec nq[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nq[j] = load(nx + j);
-                    RTK_SCHED_BARRIER();
-#pragma unroll
-                    for (int j = 1; j < 4; ++j) filter_one(f, q[j].x, q[j].y, q[j].z, q[j].w, m);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) q[j] = nq[j];
-                }
-#else
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const auto s = load(w * 32 + i);
                     filter_one(f, s.x, s.y, s.z, s.w, m);
                 }
-#endif
                 RTK_STAT(lane, filter_words);
                 emit(base + w * 32, to_cand(m, 0xFFFFFFFFu));
             }
@@ -332,92 +202,6 @@ struct Intersector {
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
-#if RTK_FILTER_FORM == 2
-        // Pair records: word w of 32 spheres owns records [16 w, 16 w + 16); in a word of `cnt` spheres, pair k holds
-        // sphere k in its HIGH halves and sphere np + k in its LOW halves, np = ceil(cnt / 2) — so that after np steps the
-        // mask has the first np spheres in bits 31.. and the rest in bits 15.. (for a full word that IS the usual
-        // MSB-first order; a partial last word shifts its low half up).
-        auto scan_pairs = [&](auto&& loadq, int count) {
-            const int full = count >> 5, rem = count & 31, last_word = (count - 1) >> 5;
-            uint32_t aw = RTK_ALWAYS_LOAD(0);     // the always-mask of word w is requested one word ahead
-            for (int w = 0; w < full; ++w) {
-                if (w * 32 - list_base > 65535 - 64) {
-                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
-                    list_base = w * 32;
-                }
-                uint32_t m = aw;
-                aw = RTK_ALWAYS_LOAD(w < last_word ? w + 1 : w);
-                // kPairGroup pairs at a time, stage by stage (dependent packed-f16 instructions need an independent one
-                // between them on gfx950), with the next group's records already requested
-                typedef decltype(loadq(0)) Rec;
-                Rec q[kPairGroup];
-#pragma unroll
-                for (int j = 0; j < kPairGroup; ++j) q[j] = loadq(w * 16 + j);
-#pragma unroll
-                for (int g = 0; g < 16 / kPairGroup; ++g) {
-                    // last group: re-reads itself, never beyond the word
-                    const int nx = w * 16 + kPairGroup * (g + 1 < 16 / kPairGroup ? g + 1 : g);
-                    Rec nq[kPairGroup];
-                    H2 x[kPairGroup], y[kPairGroup];
-#if RTK_SMEM && !defined(RTK_HOST_EMULATION)
-                    // scalar loads: a wait for one is a wait for all, so the next group is requested right after the
-                    // wait for this one (forced by the first stage) and stays in flight behind the other stages
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
-                    RTK_SCHED_BARRIER();
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
-                    RTK_SCHED_BARRIER();
-#else
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) nq[j] = loadq(nx + j);
-                    RTK_SCHED_BARRIER();      // LDS reads return in order: keep these requests ahead of the arithmetic on the previous group
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].x), f.a1, f.n1);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].x), f.a2, f.n2);
-#endif
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].y), f.b1, x[j]);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].y), f.b2, y[j]);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(h2_from_bits(q[j].z), f.c1, x[j]);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) y[j] = h2_fma(h2_from_bits(q[j].z), f.c2, y[j]);
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) x[j] = h2_fma(x[j], x[j], h2_from_bits(q[j].w));
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) {
-                        const int k = kPairGroup * g + j;
-                        m |= (h2_bits(h2_fma(y[j], y[j], x[j])) >> k) & (0x80008000u >> k);
-                    }
-#pragma unroll
-                    for (int j = 0; j < kPairGroup; ++j) q[j] = nq[j];
-                }
-                RTK_STAT(lane, filter_words);
-                emit(w * 32, to_cand(m, 0xFFFFFFFFu));
-            }
-            if (rem) {
-                const int np = (rem + 1) >> 1;
-                uint32_t m = 0;
-#pragma unroll 2
-                for (int k = 0; k < np; ++k) {
-                    const auto q = loadq(full * 16 + k);
-                    const uint32_t d = filter_pair_f16(f, q.x, q.y, q.z, q.w);
-                    m |= __builtin_amdgcn_alignbit(d, d, k) & (0x80008000u >> k);
-                }
-                m = ((m & 0xFFFF0000u) | ((m & 0xFFFFu) << (16 - np))) | aw;
-                emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
-            }
-        };
-        if (fb.f16_ok) {
-            scan_pairs([&](int j) { return RTK_FILT_LOAD(j); }, n);
-        } else
-#endif
-#if RTK_STAGED_LARGE
         if (!LDS) {
             // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced
             // global load per 64 spheres instead of one broadcast load per sphere — and filters from LDS as usual.
@@ -453,10 +237,8 @@ struct Intersector {
                 }
                 scan([&](int i) { return stage[i]; }, base, count);
             }
-        } else
-#endif
-        {
-            scan([&](int i) { return RTK_FILT_LOAD(i); }, 0, n);
+        } else {
+            scan([&](int i) { return filt[i]; }, 0, n);
         }
         flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         t_out = closest;

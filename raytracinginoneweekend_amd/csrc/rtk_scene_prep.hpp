@@ -4,7 +4,6 @@
 
 #include "rtk_device.hpp"
 #include "rtk_intersect.hpp"
-#include "rtk_f16.hpp"
 
 #include "../../include/rtk.h"
 
@@ -19,7 +18,6 @@ namespace rtk {
 struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
     std::vector<char> filterable;    // per sphere: finite, moderate, not an outlier (the filter / the grid may cull it)
-    std::vector<uint32_t> always_mask;   // RTK_FILTER_FORM == 2 with fb.f16_ok: [npad / 32], MSB = first sphere of the word
     FilterBounds fb;
     int n = 0, npad = 0;
 };
@@ -86,84 +84,6 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out) {
         volatile float inv_v = 1.0f / r;             // fl(1/radius), Vector3.cpp:36
         m1[i] = make_float4(s->metallic[i], s->ior[i], tyf, inv_v);
     }
-#if RTK_FILTER_FORM == 2
-    // Packed-f16 records (form 2) when the scene allows: filter space = (x - cen) * scale with the
-    // scene's reach scaled into [2^7, 2^8); the chain adds the coordinate of largest extent first and the smallest last.
-    if (!order.empty()) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int i : order) {
-            const double c[3] = {s->cx[i], s->cy[i], s->cz[i]};
-            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k]); }
-        }
-        float cen[3];
-        for (int k = 0; k < 3; ++k) cen[k] = static_cast<float>(0.5 * (lo[k] + hi[k]));
-        double reach = 0.0, r_min = 1e300, r_max = 0.0, ext[3] = {0, 0, 0};
-        for (int i : order) {
-            const double c[3] = {s->cx[i] - static_cast<double>(cen[0]), s->cy[i] - static_cast<double>(cen[1]), s->cz[i] - static_cast<double>(cen[2])};
-            const double rad = std::fabs(static_cast<double>(s->radius[i]));
-            reach = std::max(reach, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + rad);
-            for (int k = 0; k < 3; ++k) ext[k] = std::max(ext[k], std::fabs(c[k]));
-            r_min = std::min(r_min, rad);
-            r_max = std::max(r_max, rad);
-        }
-        int e2 = 0;
-        (void)std::frexp(reach, &e2);                                   // reach = m 2^e2, m in [0.5, 1)
-        const double scale = std::ldexp(1.0, 8 - e2);                   // reach * scale in [2^7, 2^8)
-        int ax[3] = {0, 1, 2};
-        std::sort(ax, ax + 3, [&](int x, int y) { return ext[x] > ext[y]; });
-        const bool ok = std::isfinite(scale) && scale > 0x1p-100 && scale < 0x1p100 && r_min * scale >= 0.25;
-        if (ok) {
-            fb.f16_ok = 1;
-            for (int k = 0; k < 3; ++k) { fb.cen[k] = cen[k]; fb.ax[k] = ax[k]; fb.cmax_s[k] = 0.0f; }
-            fb.scale = static_cast<float>(scale);
-            fb.c_max_s = static_cast<float>(reach * scale * (1.0 + 0x1p-20));
-            fb.r_min_s = static_cast<float>(r_min * scale * (1.0 - 0x1p-20));
-            fb.r_max2_s = static_cast<float>(r_max * scale * r_max * scale * (1.0 + 0x1p-20));
-            // per sphere: quantised centre in chain order and kappa = -rho^2 (binary16, magnitude rounded up)
-            std::vector<uint16_t> h0(npad, 0), h1(npad, 0), h2(npad, 0), hk(npad, 0x7C00);     // default: centre 0, kappa +inf = never a candidate
-            out.always_mask.assign(npad / 32, 0u);
-            for (int i = 0; i < n; ++i) {
-                if (!filterable[i]) {
-                    out.always_mask[i >> 5] |= 0x80000000u >> (i & 31);      // passed on for every ray, outside the arithmetic
-                    continue;
-                }
-                const double c[3] = {(s->cx[i] - static_cast<double>(cen[0])) * scale, (s->cy[i] - static_cast<double>(cen[1])) * scale,
-                                     (s->cz[i] - static_cast<double>(cen[2])) * scale};
-                uint16_t hb[3];
-                double dq2 = 0.0;
-                for (int k = 0; k < 3; ++k) {
-                    hb[k] = rtk_f16::from_float(static_cast<float>(c[ax[k]]));
-                    const double q = rtk_f16::to_float(hb[k]);
-                    dq2 += (q - c[ax[k]]) * (q - c[ax[k]]);
-                    fb.cmax_s[k] = std::fmax(fb.cmax_s[k], static_cast<float>(std::fabs(q)));
-                }
-                // rho = (r + 1.5 |c_hat - c|) (1 + 2^-8): the centre's quantisation is this sphere's own, known exactly; the
-                // factor covers the 3u|p| chain term, subnormal steps and the two roundings of p1^2 + p2^2 - rho^2
-                const double rho = (std::fabs(static_cast<double>(s->radius[i])) * scale + 1.5 * std::sqrt(dq2)) * (1.0 + 0x1p-8);
-                uint16_t kb = rtk_f16::from_float(static_cast<float>(rho * rho));
-                if (static_cast<double>(rtk_f16::to_float(kb)) < rho * rho) ++kb;      // next binary16 up (0x7C00 = +inf at the top: harmless)
-                h0[i] = hb[0]; h1[i] = hb[1]; h2[i] = hb[2];
-                hk[i] = static_cast<uint16_t>(kb | 0x8000u);                           // -rho^2
-            }
-            // pair records: word w owns records [16 w, 16 w + 16); pair k = sphere k (high halves) and sphere np + k (low halves)
-            for (int i = 0; i < npad; ++i) filt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int w = 0; w * 32 < n; ++w) {
-                const int base = w * 32, cnt = std::min(32, n - base), np = (cnt + 1) / 2;
-                for (int k = 0; k < np; ++k) {
-                    const int hi_i = base + k, lo_i = base + np + k;
-                    const bool has_lo = lo_i < base + cnt;
-                    auto pack = [&](const std::vector<uint16_t>& v, uint16_t absent) {
-                        const uint32_t u = (static_cast<uint32_t>(v[hi_i]) << 16) | (has_lo ? v[lo_i] : absent);
-                        float f;
-                        std::memcpy(&f, &u, 4);
-                        return f;
-                    };
-                    filt[w * 16 + k] = make_float4(pack(h0, 0), pack(h1, 0), pack(h2, 0), pack(hk, 0x7C00));
-                }
-            }
-        }
-    }
-#endif
     out.fb = fb;
     out.filterable = filterable;
 }

@@ -52,15 +52,23 @@ struct Emul {
     GridHost grid;
 };
 
-static Intersector<false> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
-    Intersector<false> it;
+// Which instantiation a scene runs on: the GPU takes Intersector<true> (operands straight from the LDS copy) up to
+// kMaxLdsSpheres and Intersector<false> (list streamed through a wave-private chunk) beyond.  The emulation follows
+// that rule unless the staged path is forced for every scene (the 64-lane build and asan_driver_staged do, so that its
+// cross-lane chunk logic is exercised on the small fixtures too).
+#ifndef EMUL_FORCE_STAGED
+#define EMUL_FORCE_STAGED (RTK_LANES == 64)
+#endif
+static bool g_force_staged = EMUL_FORCE_STAGED;
+static bool use_lds_path(const Emul& e) { return !g_force_staged && e.ps.n <= kMaxLdsSpheres; }
+
+template <bool LDS>
+static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
+    Intersector<LDS> it;
     it.filt = e.ps.filt.data();
-    it.filt_global = e.ps.filt.data();
     it.exact = e.ps.exact.data();
-    it.always = e.ps.always_mask.empty() ? nullptr : e.ps.always_mask.data();
     it.list = list;
     it.fb = e.ps.fb;
-    it.fb_mem = &e.ps.fb;
     it.n = e.ps.n;
     it.lane = lane;
     it.stage = stage;
@@ -94,6 +102,7 @@ void emul_grid_info(void* h, int64_t* info8) {
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
 
 void emul_set_ulp_noise(int k) { rtk_shim::ulp_noise = k; }
+void emul_force_staged(int on) { g_force_staged = on != 0; }
 
 // filter bounds and per-sphere "filterable" flag as prepare_scene decided them
 void emul_scene_info(void* h, float* bounds3, uint8_t* filterable) {
@@ -112,12 +121,12 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
     std::vector<float4> stage(kStageSpheres);
     std::vector<uint32_t> ne_lane(kWave, 0);
     uint64_t total = 0;
+    const bool lds = use_lds_path(e);
     for (uint64_t base = 0; base < n; base += kWave) {
         run_lanes([&](int lane) {
             const uint64_t i = base + static_cast<uint64_t>(lane);
             const bool active = i < n;
-            const Intersector<false> it = make_isect(e, list.data(), (flags && active) ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr, lane,
-                                                     RTK_STAGED_LARGE ? stage.data() : nullptr);
+            uint8_t* dbg = (flags && active) ? flags + i * static_cast<uint64_t>(e.ps.n) : nullptr;
             Ray r = {};
             if (active) {
                 const float* q = rays + 6 * i;
@@ -126,8 +135,15 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
             float tt;
             int idx;
             uint32_t ne = 0;
-            if (accel) it.closest_hit_grid(e.grid.dev, r, active, t_min, t_max, tt, idx, ne);
-            else it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
+            if (lds) {
+                const Intersector<true> it = make_isect<true>(e, list.data(), dbg, lane);
+                if (accel) it.closest_hit_grid(e.grid.dev, r, active, t_min, t_max, tt, idx, ne);
+                else it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
+            } else {
+                const Intersector<false> it = make_isect<false>(e, list.data(), dbg, lane, stage.data());
+                if (accel) it.closest_hit_grid(e.grid.dev, r, active, t_min, t_max, tt, idx, ne);
+                else it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
+            }
             ne_lane[lane] = ne;
             if (active) {
                 hit[i] = idx >= 0;
@@ -214,15 +230,22 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     A.stats = stats;
     A.dbg_seg = seg_counts;
     A.grid = e.grid.dev;
+    const bool lds = use_lds_path(e);
     std::vector<std::thread> pool;
     for (int k = 0; k < threads; ++k)
         pool.emplace_back([&] {
             std::vector<uint16_t> list(kListCap * kWave);
             std::vector<float4> stage(kStageSpheres);
             run_lanes([&](int lane) {
-                const Intersector<false> it = make_isect(e, list.data(), nullptr, lane, RTK_STAGED_LARGE ? stage.data() : nullptr);
-                if (accel) render_wave<false, true>(A, it, &A.cam);
-                else render_wave<false, false>(A, it, &A.cam);
+                if (lds) {
+                    const Intersector<true> it = make_isect<true>(e, list.data(), nullptr, lane);
+                    if (accel) render_wave<true, true>(A, it, &A.cam);
+                    else render_wave<true, false>(A, it, &A.cam);
+                } else {
+                    const Intersector<false> it = make_isect<false>(e, list.data(), nullptr, lane, stage.data());
+                    if (accel) render_wave<false, true>(A, it, &A.cam);
+                    else render_wave<false, false>(A, it, &A.cam);
+                }
             });
             fold_stats();
         });

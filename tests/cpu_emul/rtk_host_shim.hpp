@@ -81,34 +81,6 @@ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return static_
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #endif
 
-// Packed binary16 pairs (RTK_FILTER_FORM == 2): both halves are kept as floats that are exactly representable in
-// binary16.  v_pk_fma_f16 = one rounding per half (subnormals kept); v_dot2_f32_f16 accumulates in f32.  Under
-// emul_set_ulp_noise(k) every f16 result is perturbed by up to +-k binary16 ulps and the dot product by +-k f32 ulps.
-#include "rtk_f16.hpp"
-struct H2 { float lo, hi; };
-namespace rtk_shim {
-inline float nudge16(float x) {
-    if (ulp_noise == 0 || !(x == x) || std::isinf(x) || x == 0.0f) return x;
-    noise_state = noise_state * 1664525u + 1013904223u;
-    const int k = static_cast<int>((noise_state >> 16) % static_cast<uint32_t>(2 * ulp_noise + 1)) - ulp_noise;
-    const uint16_t h = rtk_f16::from_float(x);
-    const int mag = static_cast<int>(h & 0x7FFFu) + k;
-    if (mag <= 0 || mag >= 0x7C00) return x;
-    return rtk_f16::to_float(static_cast<uint16_t>((h & 0x8000u) | static_cast<uint16_t>(mag)));
-}
-inline float fma16(float a, float b, float c) {
-    return nudge16(rtk_f16::round(static_cast<float>(std::fma(static_cast<double>(a), static_cast<double>(b), static_cast<double>(c)))));
-}
-} // namespace rtk_shim
-inline H2 h2_splat(float v) { const float h = rtk_f16::round(v); return {h, h}; }
-inline H2 h2_from_bits(float bits) {
-    const uint32_t u = __float_as_uint(bits);
-    return {rtk_f16::to_float(static_cast<uint16_t>(u & 0xFFFFu)), rtk_f16::to_float(static_cast<uint16_t>(u >> 16))};
-}
-inline uint32_t h2_bits(H2 v) { return static_cast<uint32_t>(rtk_f16::from_float(v.lo)) | (static_cast<uint32_t>(rtk_f16::from_float(v.hi)) << 16); }
-inline float h2_lo(H2 v) { return v.lo; }
-inline H2 h2_fma(H2 a, H2 b, H2 c) { return {rtk_shim::fma16(a.lo, b.lo, c.lo), rtk_shim::fma16(a.hi, b.hi, c.hi)}; }
-
 // Dynamic wave-level statistics of the emulated kernels (how often each block of the pass executes for a wave).
 namespace rtk_shim {
 struct WaveStats {

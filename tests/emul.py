@@ -20,8 +20,7 @@ def lib(lanes=1):
     """lanes = 1: one lane per wave (fast).  lanes = 64: 64 fibers per wave meeting at the votes (cross-lane logic)."""
     if lanes not in _libs:
         subprocess.run(["make", "-C", os.path.join(HERE, "cpu_emul")], check=True, capture_output=True)
-        # lanes: 1 / 64, or "f2" / "f2x64" = the packed-f16 filter build (RTK_FILTER_FORM=2) with 1 / 64 lanes per wave
-        l = C.CDLL(os.path.join(HERE, "cpu_emul", {1: "libemul.so", 64: "libemul64.so", "f2": "libemul_f2.so", "f2x64": "libemul64_f2.so"}[lanes]))
+        l = C.CDLL(os.path.join(HERE, "cpu_emul", {1: "libemul.so", 64: "libemul64.so"}[lanes]))
         vp = C.c_void_p
         l.emul_create.restype = vp
         l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]

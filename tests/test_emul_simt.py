@@ -63,8 +63,8 @@ def test_wave_statistics_are_sane(e64):
     assert 1.0 < s["flush_iters"] / st["passes"] < 12.0
 
 
-# ---- RTK_STAGED_LARGE: libemul64.so is built with the staged large-scene path, so every 64-lane intersect above
-# already went through it (the emulation has no LDS-resident scene); these cases add the chunk boundaries. ----
+# ---- the staged large-scene path: libemul64.so forces it for every scene (EMUL_FORCE_STAGED), so every 64-lane
+# intersect above already went through it; these cases add the chunk boundaries. ----
 @pytest.mark.parametrize("n", [1, 63, 127, 128, 129, 160, 255, 256, 257, 1025])
 def test_staged_chunks_and_tails(n):
     """Scenes around the 128-sphere chunk size: last chunk of 1, of a partial word, of exactly one chunk."""

@@ -153,8 +153,14 @@ def test_quantiser_byte_exact_vs_reference(gpu_ctx):
     assert np.array_equal(out.cpu().numpy(), z["bytes"])
 
 
-def test_full_size_config2_properties(gpu_ctx, golden):
-    """BASELINE.json config 2 (1200 x 800, 500 spp, depth 50) at full size: size-independent properties."""
+def test_full_size_config2_image_gate_and_properties(gpu_ctx, golden):
+    """BASELINE.json config 2 (1200 x 800, 500 spp, depth 50) at full size.
+    Image gate AT THE HEADLINE GEOMETRY: four row bands of the real 1200 x 800 frame (upper scene, two bands through the
+    three big spheres, small spheres in front; 48 rows, 57 600 pixels) rendered by the hash-pinned oracle at 2000 spp in
+    8 decorrelated streams (tools/make_golden.py golden_bands -> tests/golden/bands_1200x800_2000spp.npz).
+    Tolerance (north_star): PSNR >= 40 dB <=> 8-bit RMSE <= 2.55 of the quantised 500-spp GPU rows against the
+    quantised golden rows (write_color_binary bytes, Color.hpp:28-48); two independent 500-spp / 2000-spp renders are
+    expected at ~44.5 dB (SURVEY.md §7 hard part 4).  Plus size-independent properties."""
     gsum, gspp, depth, gseg = golden
     W, H, spp = 1200, 800, 500
     cam = rt.stock_camera(W / H)
@@ -163,14 +169,23 @@ def test_full_size_config2_properties(gpu_ctx, golden):
     assert abs(st["rays"] / st["samples"] - gseg) < 0.01 * gseg
     # every sample's radiance is in [0, 1]^3 for this scene (albedos and sky <= 1)
     assert img.min() >= 0 and img.max() <= spp * (1 + 1e-5)
-    # about the same mean radiance as the low-resolution CPU golden; not the same field of view: u spans
-    # [0, W/(W-1)] (main.cpp:69), 0.8 % wider at W = 120 than at W = 1200, so only a loose bound applies
-    assert np.allclose((img / spp).mean((0, 1)), (gsum / gspp).mean((0, 1)), rtol=3e-2)
-    # box-downsampled 10x it is the golden's picture (edges are mis-registered by (W-1) vs (w-1): loose bound)
-    small = img.reshape(80, 10, 120, 10, 3).mean((1, 3))
-    psnr_small = po.psnr_u8(po.quantise(small, spp), po.quantise(gsum, gspp))
-    print("10x box-downsampled vs golden: %.2f dB" % psnr_small)
-    assert psnr_small > 22.0          # measured 25.8 dB: mis-registration, not noise
+    z = load_golden("bands_1200x800_2000spp.npz")
+    assert int(z["width"]) == W and int(z["height"]) == H and int(z["depth"]) == depth
+    rows = np.concatenate([np.arange(b, e) for b, e in z["bands"]])
+    got_u8 = po.quantise(img[rows], spp)
+    want_u8 = po.quantise(z["rgb_sum"], int(z["spp"]))
+    psnr = po.psnr_u8(got_u8, want_u8)
+    rmse = float(np.sqrt(np.mean((got_u8.astype(np.float64) - want_u8.astype(np.float64)) ** 2)))
+    print("1200x800 bands, 500 spp GPU vs 2000 spp oracle: PSNR %.2f dB, 8-bit RMSE %.3f" % (psnr, rmse))
+    assert psnr >= 40.0 and rmse <= 2.55
+    # every band separately clears the gate minus the small-sample allowance (a band is 9 600 - 19 200 pixels)
+    o = 0
+    for b, e in z["bands"]:
+        k = int(e - b)
+        assert po.psnr_u8(got_u8[o:o + k], want_u8[o:o + k]) >= 39.0, (int(b), int(e))
+        o += k
+    # no bias: the bands' mean linear radiance agrees to 0.5 %
+    assert np.allclose((img[rows] / spp).mean((0, 1)), (z["rgb_sum"] / float(z["spp"])).mean((0, 1)), rtol=5e-3)
     # idempotence: the same call again gives the same bits
     img2, st2 = gpu_ctx.render(cam, W, H, spp, depth, seed=11)
     assert np.array_equal(bits(img), bits(img2)) and st["rays"] == st2["rays"]

@@ -2,15 +2,14 @@
 # tools/gpu_session.sh <stage> [tag] — the GPU steps of a round, each under its own time limit, stopping at the first
 # failure (nothing more is started on the GPU after a fault, abort or time-out).  Run through gpurun, e.g.
 #   gpurun --timeout 900 -- 'bash tools/gpu_session.sh verify r02'
-# Build everything on the CPU first: python -m raytracinginoneweekend_amd.build && python tools/build_variants.py &&
+# Build everything on the CPU first: python -m raytracinginoneweekend_amd.build && python tools/build_variants.py <specs> &&
 #   hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/bin/valu_rates
 # Stages:
 #   smoke    __graft_entry__.smoke(): one small invocation against the oracle     -> gpurun_out/<tag>_smoke.log
 #   verify   GPU tests, then the headline bench line                       -> gpurun_out/<tag>_tests.log, <tag>_bench.json
 #   rates    issue rates of candidate filter instructions                  -> gpurun_out/<tag>_valu_rates.txt
-#   ab       interleaved A/B of the kernel variants at 100 spp             -> gpurun_out/<tag>_ab.txt
+#   variants parity tests of each named experiment build, then their interleaved A/B -> gpurun_out/<tag>_tests_<name>.log, <tag>_ab_*.txt
 #   profile  rocprofv3 kernel trace + PMC passes (tools/profile.sh)        -> gpurun_out/prof_<tag>/
-#   variant  GPU parity tests + bench of one experiment build (3rd argument)   -> gpurun_out/<tag>_tests_<name>.log, _bench_<name>.json
 #   config4  list walk vs uniform grid on the 10k-sphere scene             -> gpurun_out/<tag>_config4_*.json
 #   overlap  one vs two frames in flight, full frame and an eighth of it   -> gpurun_out/<tag>_overlap*.json
 set -u
@@ -35,19 +34,19 @@ case "$STAGE" in
   rates)
     step 120 gpurun_out/${TAG}_valu_rates.txt tools/bin/valu_rates 4 20000
     step 120 gpurun_out/${TAG}_valu_rates_1wave.txt tools/bin/valu_rates 1 20000 ;;
-  ab)
-    step 900 gpurun_out/${TAG}_ab.txt python tools/ab_bench.py 100 2 ;;
+  variants)  # gpu_session.sh variants <tag> <spp> <name> [<name> ...]: GPU parity tests against each named build; the A/B afterwards
+             # times only builds that passed (the first failure ends the call: nothing more is started on the GPU)
+    SPP=${3:?spp}; shift 3
+    for NAME in "$@"; do
+      step 600 gpurun_out/${TAG}_tests_${NAME}.log env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_${NAME}.so python -u -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py -m gpu -x -q --timeout 120 --timeout-method thread
+    done
+    step 900 gpurun_out/${TAG}_ab_$(echo "$@" | tr ' ' '_').txt python tools/ab_bench.py $SPP 2 "$@" ;;
   profile)
     bash tools/profile.sh "$TAG" || exit 1 ;;
   config4)
     step 300 gpurun_out/${TAG}_config4_list.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
-    step 300 gpurun_out/${TAG}_config4_staged.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_staged.so python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline
     step 300 gpurun_out/${TAG}_config4_grid.json python bench.py --scene-k 50 --width 400 --height 225 --spp 16 --steps 3 --warmup 1 --no-cpu-baseline --accel grid
     step 300 gpurun_out/${TAG}_stock_grid.json python bench.py --accel grid --no-cpu-baseline ;;
-  variant)   # gpu_session.sh variant <tag> <name>: the GPU parity tests against an experiment build before it is timed
-    NAME=${3:?variant name (f16, smem, exactg, staged)}
-    step 900 gpurun_out/${TAG}_tests_${NAME}.log env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_${NAME}.so python -u -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py -m gpu -x -q --timeout 120 --timeout-method thread
-    step 300 gpurun_out/${TAG}_bench_${NAME}.json env RTK_LIB=$PWD/raytracinginoneweekend_amd/variants/librtk_${NAME}.so python bench.py --no-cpu-baseline ;;
   overlap)
     step 300 gpurun_out/${TAG}_overlap1.json python bench.py --no-cpu-baseline
     step 300 gpurun_out/${TAG}_overlap2.json python bench.py --no-cpu-baseline --frames-in-flight 2

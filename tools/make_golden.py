@@ -324,7 +324,43 @@ def golden_image(W=120, H=80, parts=8, spp_part=250, depth=50):
     print("golden image", W, H, spp, "segments/sample %.4f" % (segs / (W * H * spp)))
 
 
+def _band_part(args):
+    part, W, H, spp, depth, bands = args
+    from oracle import pyoracle as po
+    o = po.Oracle()
+    o.random_scene()
+    o.discard(part * 400_000_000, part * 400_000_000 + 7)      # decorrelated streams, as _golden_part
+    out, segs = [], 0
+    for b, e in bands:
+        sums, _, seg = o.render_rows(po.stock_camera(W / H), W, H, spp, depth, b, e, want_u8=False)
+        out.append(sums.astype(np.float64))
+        segs += seg
+    return np.concatenate(out, axis=0), segs
+
+
+# Bands (image rows from the top, [begin, end)) of the REAL 1200x800 frame of BASELINE.json configs[1]: upper part of
+# the scene, two bands through the three big spheres (glass / diffuse / metal), small spheres on the ground in front.
+BANDS_1200x800 = ((248, 256), (392, 408), (448, 456), (616, 632))
+
+
+def golden_bands(W=1200, H=800, parts=8, spp_part=250, depth=50, bands=BANDS_1200x800):
+    """Linear-float golden of a few row bands at the headline geometry from the hash-pinned oracle (for the >= 40 dB gate
+    on the full-size GPU frame): parts x spp_part samples per pixel in decorrelated streams."""
+    with mp.get_context("spawn").Pool(min(parts, 8)) as pool:
+        res = pool.map(_band_part, [(p, W, H, spp_part, depth, bands) for p in range(parts)])
+    total = sum(r[0] for r in res)
+    segs = sum(r[1] for r in res)
+    spp = parts * spp_part
+    rows = sum(e - b for b, e in bands)
+    np.savez_compressed(os.path.join(GOLD, f"bands_{W}x{H}_{spp}spp.npz"), rgb_sum=total.astype(np.float32), spp=np.int32(spp), depth=np.int32(depth),
+                        bands=np.asarray(bands, np.int32), width=np.int32(W), height=np.int32(H), segments=np.int64(segs))
+    print("golden bands", W, H, spp, bands, "segments/sample %.4f" % (segs / (W * rows * spp)))
+
+
 if __name__ == "__main__":
+    if "--bands-only" in sys.argv:
+        golden_bands()
+        sys.exit(0)
     if "--image-only" not in sys.argv:
         main()
     if "--no-image" not in sys.argv:

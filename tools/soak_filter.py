@@ -1,7 +1,7 @@
 """Randomised soak of the filter's conservativeness and the intersector's parity on the CPU build of the device
 code (tests/cpu_emul): random scenes (sizes, scales, offsets, radius spreads), random + tangent + surface rays,
 +-3 ulp perturbation of the hardware approximations.  Prints a summary line per scene; exits non-zero on any miss.
-usage: python tools/soak_filter.py [n_scenes] [seed] [build]     build: 1 (default, shipped f32 filter) or f2 (packed-f16 filter)"""
+usage: python tools/soak_filter.py [n_scenes] [seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,9 +12,8 @@ from test_emul_intersect import tangent_rays
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-build = sys.argv[3] if len(sys.argv) > 3 else "1"
-build = "f2" if build == "f2" else 1
-noise = 2 if build == "f2" else 3        # binary16 ulps for f2 (4x the rounding its margins assume), f32 ulps otherwise
+build = 1
+noise = 3        # f32 ulps added to every hardware approximation
 pairs = rays_total = 0
 t0 = time.time()
 for it in range(n_scenes):
