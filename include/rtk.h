@@ -157,6 +157,20 @@ int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len
 int rtk_render_tiles_device(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
                             rtk_stats* stats);
 
+/* The same render for callers that CANNOT ALLOCATE device memory — code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference (it has no device).  Arguments, output layout, bits
+ * of the result and asynchrony are those of rtk_render_tiles_device; the difference is where the kernels' working
+ * memory lives: pixel accumulators, packet queue, counters and the run table sit in ONE static device array of the
+ * library (24 MiB + 8.5 KiB per GPU, held until the process ends) instead of context buffers grown with hipMalloc.
+ * The call makes no hipMalloc / hipFree and no allocating library call (rtk_set_scene, which does allocate, must have
+ * run before; pass stats = NULL to also avoid the 32-byte counter read-back and its synchronisation).
+ * Limits: at most RTK_NOALLOC_MAX_TILES local tiles (1 048 576 pixels of this rank; 1200 x 800 fits) and 1024 sample
+ * runs per pixel -> RTK_ERR_TOO_LARGE beyond.  Every call on a GPU shares that GPU's array: the call clears what it
+ * needs at its start, and CALLS THAT OVERLAP ON ONE GPU (two contexts, two streams) RACE — serialise them. */
+#define RTK_NOALLOC_MAX_TILES 16384
+int rtk_render_tiles_device_noalloc(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
+                                    rtk_stats* stats);
+
 /* Counters accumulate over frames rendered with stats == NULL.  rtk_reset_stats zeroes them (asynchronous);
  * rtk_get_stats synchronises the stream and reads them, with the render kernel's HIP-event time summed
  * over the frames since the reset.  (A render call that is GIVEN a stats pointer resets, renders, reads.) */

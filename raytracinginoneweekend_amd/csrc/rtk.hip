@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -161,6 +162,21 @@ __global__ void philox_kernel(uint32_t seed_lo, uint32_t seed_hi, const uint32_t
     out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
 }
 
+// ---- rtk_render_tiles_device_noalloc: every byte of device memory the render kernels need beyond the caller's inputs
+// and outputs, in ONE static device array (per GPU, held until the process ends):
+//   [0, 256) packet queue | [256, 512) counters | [512, 512 + 8 kNoAllocMaxRuns) run table | pixel accumulators.
+constexpr int kNoAllocMaxTiles = RTK_NOALLOC_MAX_TILES;          // 64-pixel tiles of one call (rtk.h)
+constexpr int kNoAllocMaxRuns = 1024;                             // runs of a pixel's samples
+constexpr size_t kScratchRunsOff = 512;
+constexpr size_t kScratchAccumOff = kScratchRunsOff + sizeof(uint2) * kNoAllocMaxRuns;
+constexpr size_t kScratchBytes = kScratchAccumOff + static_cast<size_t>(kNoAllocMaxTiles) * kTilePixels * 3 * sizeof(unsigned long long);
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// The run table of (spp, W, H, run_len), written by one thread into the static array (no host table, no copy).
+__global__ void runs_kernel(int spp, int width, int height, int run_len, uint2* out, int cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fill_runs(spp, width, height, run_len, out, cap);
+}
+
 // =================================================================================================
 // Host side of the C ABI
 // =================================================================================================
@@ -267,6 +283,32 @@ static int upload_grid(rtk_context* c) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false, true>, kBlockThreads, lds_bytes(false, c->scene.npad)));
     c->blocks_per_cu_grid = nb > 0 ? nb : 1;
     c->grid_ok = true;
+    return RTK_OK;
+}
+
+// Counters of the render kernels since they were last cleared (`d_counters`: 4 u64 in device memory) and the HIP-event
+// times of the context's frames.  Synchronises the context's stream.
+static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_counters) {
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    stats->rays = h[0];
+    stats->samples = h[1];
+    // list walk: every ray meets every sphere; grid: only the exact tests of the cells it crosses
+    stats->sphere_tests = use_grid(c) ? h[2] : h[0] * static_cast<uint64_t>(c->scene.n);
+    stats->exact_tests = h[2];
+    stats->lane_slots = h[3] * kWave;
+    stats->frames = static_cast<uint32_t>(c->n_frames);
+    stats->kernel_ms = 0.0f;
+    stats->total_ms = 0.0f;
+    const int timed = c->n_frames < rtk_context::kEventPairs ? c->n_frames : rtk_context::kEventPairs;
+    for (int i = 0; i < timed; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
+        stats->kernel_ms += ms;
+    }
+    stats->frames_timed = static_cast<uint32_t>(timed);
     return RTK_OK;
 }
 
@@ -427,7 +469,9 @@ int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len
     return n;
 }
 
-int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats) {
+// `static_ws`: the device address of this GPU's `scratch` array (rtk_render_tiles_device_noalloc) or null (the context's
+// own buffers, grown with hipMalloc as needed).
+static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats, unsigned char* static_ws) {
     if (!c || !cam || !p || !d_tile_sums) return fail(RTK_ERR_BAD_ARG, "rtk_render_tiles_device: null argument");
     if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_render_tiles_device: call rtk_set_scene first");
     if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
@@ -443,34 +487,62 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     const int tiles_x = (p->width + tw - 1) / tw;
     const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, p->rank, world);
     if (p->run_len < 0) return fail(RTK_ERR_BAD_ARG, "run_len must be >= 0, got %d", p->run_len);
-    if (c->runs_key[0] != p->spp || c->runs_key[1] != p->width || c->runs_key[2] != p->height || c->runs_key[3] != p->run_len) {
-        // a new sample partition: upload its table (the stream may still be reading the old one)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->runs_host = run_schedule(p->spp, p->width, p->height, p->run_len);
-        HIP_TRY(c->runs.reserve(c->runs_host.size() * sizeof(uint2)));
-        HIP_TRY(hipMemcpy(c->runs.p, c->runs_host.data(), c->runs_host.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        c->runs_key[0] = p->spp; c->runs_key[1] = p->width; c->runs_key[2] = p->height; c->runs_key[3] = p->run_len;
+    int n_runs = 0;
+    if (static_ws) {
+        n_runs = fill_runs(p->spp, p->width, p->height, p->run_len, nullptr, 0);
+        if (n_runs > kNoAllocMaxRuns) return fail(RTK_ERR_TOO_LARGE, "rtk_render_tiles_device_noalloc: %d sample runs exceed the static table of %d (use fewer spp per call or a larger run_len)", n_runs, kNoAllocMaxRuns);
+    } else {
+        if (c->runs_key[0] != p->spp || c->runs_key[1] != p->width || c->runs_key[2] != p->height || c->runs_key[3] != p->run_len) {
+            // a new sample partition: upload its table (the stream may still be reading the old one)
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->runs_host = run_schedule(p->spp, p->width, p->height, p->run_len);
+            HIP_TRY(c->runs.reserve(c->runs_host.size() * sizeof(uint2)));
+            HIP_TRY(hipMemcpy(c->runs.p, c->runs_host.data(), c->runs_host.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            c->runs_key[0] = p->spp; c->runs_key[1] = p->width; c->runs_key[2] = p->height; c->runs_key[3] = p->run_len;
+        }
+        n_runs = static_cast<int>(c->runs_host.size());
     }
-    const int n_runs = static_cast<int>(c->runs_host.size());
     const int64_t packets = nlt * n_runs;
     if (packets >= (1ll << 32) - (1ll << 20)) return fail(RTK_ERR_TOO_LARGE, "%lld packets exceed the 32-bit queue", static_cast<long long>(packets));
     const size_t n_acc = static_cast<size_t>(nlt) * kTilePixels * 3;
     if (nlt == 0) return RTK_OK;
 
-    if (n_acc * 8 > c->accum.cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(c->accum.reserve(n_acc * 8));
-        c->accum_zeroed = 0;
+    unsigned long long* accum = nullptr;
+    unsigned char* control = nullptr;
+    const uint2* runs = nullptr;
+    if (static_ws) {
+        if (nlt > kNoAllocMaxTiles) return fail(RTK_ERR_TOO_LARGE, "rtk_render_tiles_device_noalloc: %lld tiles exceed the static limit of %d (RTK_NOALLOC_MAX_TILES, %d pixels)",
+                                                static_cast<long long>(nlt), kNoAllocMaxTiles, kNoAllocMaxTiles * kTilePixels);
+        // the array keeps the last call's contents (any context, any size): clear what must start at zero
+        control = static_ws;
+        accum = reinterpret_cast<unsigned long long*>(static_ws + kScratchAccumOff);
+        uint2* rt = reinterpret_cast<uint2*>(static_ws + kScratchRunsOff);
+        runs = rt;
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(hipMemsetAsync(accum, 0, n_acc * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(control, 0, 512, c->stream));
+        hipLaunchKernelGGL(runs_kernel, dim3(1), dim3(64), 0, c->stream, p->spp, p->width, p->height, p->run_len, rt, kNoAllocMaxRuns);
+        HIP_TRY(hipGetLastError());
+        c->n_frames = 0;             // the counters are per call here
+    } else {
+        if (n_acc * 8 > c->accum.cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(c->accum.reserve(n_acc * 8));
+            c->accum_zeroed = 0;
+        }
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        if (c->accum_zeroed < n_acc) {
+            HIP_TRY(hipMemsetAsync(c->accum.p, 0, c->accum.cap, c->stream));
+            c->accum_zeroed = c->accum.cap / 8;
+        }
+        if (stats) {
+            if (int e = rtk_reset_stats(c)) return e;
+        }
+        HIP_TRY(hipMemsetAsync(c->control.p, 0, 256, c->stream));   // the packet queue; the counters behind it accumulate
+        accum = static_cast<unsigned long long*>(c->accum.p);
+        control = static_cast<unsigned char*>(c->control.p);
+        runs = static_cast<const uint2*>(c->runs.p);
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (c->accum_zeroed < n_acc) {
-        HIP_TRY(hipMemsetAsync(c->accum.p, 0, c->accum.cap, c->stream));
-        c->accum_zeroed = c->accum.cap / 8;
-    }
-    if (stats) {
-        if (int e = rtk_reset_stats(c)) return e;
-    }
-    HIP_TRY(hipMemsetAsync(c->control.p, 0, 256, c->stream));   // the packet queue; the counters behind it accumulate
 
     RenderArgs A;
     A.scene = c->scene;
@@ -484,11 +556,11 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     while ((1 << A.tile_w_log2) < tw) ++A.tile_w_log2;
     A.rank = p->rank; A.world = world;
     A.n_local_tiles = static_cast<int32_t>(nlt);
-    A.runs = static_cast<const uint2*>(c->runs.p); A.n_runs = n_runs;
+    A.runs = runs; A.n_runs = n_runs;
     A.total_packets = static_cast<uint32_t>(packets);
-    A.accum = static_cast<unsigned long long*>(c->accum.p);
-    A.queue = static_cast<uint32_t*>(c->control.p);
-    A.stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->control.p) + 256);
+    A.accum = accum;
+    A.queue = reinterpret_cast<uint32_t*>(control);
+    A.stats = reinterpret_cast<unsigned long long*>(control + 256);
 
     const bool accel = use_grid(c);
     const bool lds = use_lds(c) && !accel;
@@ -510,14 +582,45 @@ int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_par
     HIP_TRY(hipEventRecord(c->kev[2 * slot + 1], c->stream));
     ++c->n_frames;
     const unsigned fb = static_cast<unsigned>((n_acc + 255) / 256);
-    hipLaunchKernelGGL(finalize_kernel, dim3(fb), dim3(256), 0, c->stream, static_cast<unsigned long long*>(c->accum.p), d_tile_sums, n_acc);
+    hipLaunchKernelGGL(finalize_kernel, dim3(fb), dim3(256), 0, c->stream, accum, d_tile_sums, n_acc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev3, c->stream));
     if (stats) {
-        if (int e = rtk_get_stats(c, stats)) return e;
+        if (int e = read_stats(c, stats, control + 256)) return e;
         HIP_TRY(hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
     }
     return RTK_OK;
+}
+
+int rtk_render_tiles_device(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats) {
+    return render_tiles_impl(c, cam, p, d_tile_sums, stats, nullptr);
+}
+
+// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.  In host code the
+// array's NAME is only a stand-in for the symbol: the address the kernels can use comes from hipGetSymbolAddress.
+static constexpr int kMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_device(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RTK_ERR_BAD_ARG, "device %d beyond the %d the static workspace table holds", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        HIP_TRY(hipSetDevice(device));
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RTK_ERR_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return RTK_OK;
+}
+
+int rtk_render_tiles_device_noalloc(rtk_context* c, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums, rtk_stats* stats) {
+    if (!c) return fail(RTK_ERR_BAD_ARG, "rtk_render_tiles_device_noalloc: null context");
+    unsigned char* ws = nullptr;
+    if (int e = scratch_for_device(c->device, &ws)) return e;
+    return render_tiles_impl(c, cam, p, d_tile_sums, stats, ws);
 }
 
 int rtk_reset_stats(rtk_context* c) {
@@ -530,27 +633,7 @@ int rtk_reset_stats(rtk_context* c) {
 
 int rtk_get_stats(rtk_context* c, rtk_stats* stats) {
     if (!c || !stats) return fail(RTK_ERR_BAD_ARG, "rtk_get_stats: null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[4];
-    HIP_TRY(hipMemcpyAsync(h, static_cast<char*>(c->control.p) + 256, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    stats->rays = h[0];
-    stats->samples = h[1];
-    // list walk: every ray meets every sphere; grid: only the exact tests of the cells it crosses
-    stats->sphere_tests = use_grid(c) ? h[2] : h[0] * static_cast<uint64_t>(c->scene.n);
-    stats->exact_tests = h[2];
-    stats->lane_slots = h[3] * kWave;
-    stats->frames = static_cast<uint32_t>(c->n_frames);
-    stats->kernel_ms = 0.0f;
-    stats->total_ms = 0.0f;
-    const int timed = c->n_frames < rtk_context::kEventPairs ? c->n_frames : rtk_context::kEventPairs;
-    for (int i = 0; i < timed; ++i) {
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
-        stats->kernel_ms += ms;
-    }
-    stats->frames_timed = static_cast<uint32_t>(timed);
-    return RTK_OK;
+    return read_stats(c, stats, static_cast<unsigned char*>(c->control.p) + 256);
 }
 
 extern "C++" template <typename T>

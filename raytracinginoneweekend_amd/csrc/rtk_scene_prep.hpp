@@ -316,22 +316,32 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
 // sets the kernel's end; hot pixels — glass interiors — cost up to 7x the mean per sample).  k grows as the
 // frame shrinks (fewer pixels per lane -> the tail matters more): k = clamp(66.7e6 / (W*H), 8, 64), sized for
 // the frame being split over up to 8 GPUs (tools/sim_schedule.py).
-inline std::vector<uint2> run_schedule(int spp, int width, int height, int run_len) {
-    std::vector<uint2> runs;
-    if (spp <= 0) return runs;
+// fill_runs: the table itself, usable from host and device code (the entry point that allocates nothing builds it with
+// a one-thread kernel straight into its static device array).  Returns the number of runs; writes at most `cap`.
+__host__ __device__ inline int fill_runs(int spp, int width, int height, int run_len, uint2* out, int cap) {
+    int n = 0;
+    if (spp <= 0) return 0;
     if (run_len > 0) {
-        for (int s = 0; s < spp; s += run_len) runs.push_back(make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(std::min(run_len, spp - s))));
-        return runs;
+        for (int s = 0; s < spp; s += run_len, ++n)
+            if (n < cap) out[n] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(run_len < spp - s ? run_len : spp - s));
+        return n;
     }
     const double px = static_cast<double>(width) * static_cast<double>(height);
-    const int k = static_cast<int>(std::min(64.0, std::max(8.0, std::ceil(66.7e6 / std::max(1.0, px)))));
-    int s = 0;
-    while (s < spp) {
+    double kd = ceil(66.7e6 / (px > 1.0 ? px : 1.0));
+    kd = kd < 8.0 ? 8.0 : (kd > 64.0 ? 64.0 : kd);
+    const int k = static_cast<int>(kd);
+    for (int s = 0; s < spp; ++n) {
         const int rem = spp - s;
         const int len = (rem + k - 1) / k;          // >= 1
-        runs.push_back(make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(len)));
+        if (n < cap) out[n] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(len));
         s += len;
     }
+    return n;
+}
+
+inline std::vector<uint2> run_schedule(int spp, int width, int height, int run_len) {
+    std::vector<uint2> runs(static_cast<size_t>(fill_runs(spp, width, height, run_len, nullptr, 0)));
+    fill_runs(spp, width, height, run_len, runs.data(), static_cast<int>(runs.size()));
     return runs;
 }
 
