@@ -42,7 +42,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-KERNEL_TAG = "r01-c (projection filter, decreasing run schedule, fp32 fixed-point flush)"   # bump when the kernel's memory behaviour changes
+KERNEL_TAG = "r02-a (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius; decreasing run schedule)"   # bump when the kernel changes
 
 
 def cpu_baseline():
@@ -152,6 +152,11 @@ def main():
         for key in ("rays", "samples", "sphere_tests", "exact_tests", "lane_slots", "kernel_ms", "frames", "frames_timed"):
             st[key] += o[key]
 
+    per_rank_ms = [st["kernel_ms"] / max(1, st["frames_timed"])]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_ms[0])
+        per_rank_ms = [float(x) for x in gathered]
     tot = torch.tensor([float(st["rays"]), float(st["samples"]), float(st["kernel_ms"]), float(st["frames_timed"]), float(st["lane_slots"]),
                         float(st["exact_tests"])], dtype=torch.float64, device=device)
     tmax = torch.tensor([elapsed, st["kernel_ms"] / max(1, st["frames_timed"])], dtype=torch.float64, device=device)
@@ -178,6 +183,10 @@ def main():
             except Exception:
                 traffic = None
         headline = args.scene_k <= 0 and args.accel == "list"
+        lay = ctx.scene_layout()
+        n_class = 32 * lay["class_words"]
+        filt_valu = (7.0 * n_class + 8.0 * (n_spheres - n_class)) / n_spheres          # vector instructions per ray-sphere filter test
+        alg_bytes = args.width * args.height * 3 * (8 + 4) / world                       # per launch: one u64 accumulator + one fp32 sum per channel
         out = {
             "metric": "Mrays/s (whole node), final scene 1200x800 500spp" if headline else
                       "Mrays/s (whole node), NOT the headline workload: %s, %s" % ("stock scene" if args.scene_k <= 0 else "config-4 scene k=%d (%d spheres)" % (args.scene_k, n_spheres),
@@ -193,7 +202,11 @@ def main():
                        "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max, "frames_in_flight": args.frames_in_flight},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_tag": KERNEL_TAG, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-                         "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays,
+                         "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays, "per_rank_kernel_ms": per_rank_ms,
+                         "basis": "ALGORITHMIC flops (17 per ray-sphere test x spheres x rays, SURVEY.md §8d), not executed ones: the kernel runs a conservative "
+                                  "%.2f-instruction fp32 filter per test plus ~2 exact reference tests per ray; executed-fp32 fraction from counters: profiles/*_summary.md" % filt_valu,
+                         "filter_valu_per_test": filt_valu, "class_words": lay["class_words"], "lds_bytes_per_workgroup": lay["lds_bytes_per_workgroup"],
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays)},
         }
         if args.accel == "grid":
@@ -203,6 +216,7 @@ def main():
                                "note": "uniform grid: algorithmic work differs from the list walk; compare Mrays/s with --accel list on the same scene"}
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
+            out["vs_cpu_baseline"] = mrays / out["cpu_baseline"]["value"]     # vs_baseline stays null: the reference publishes no number
         print(json.dumps(out), flush=True)
     # tear down in order: the context must not outlive the torch stream it was pointed at
     torch.cuda.synchronize()

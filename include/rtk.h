@@ -134,6 +134,12 @@ enum { RTK_ACCEL_LIST = 0, RTK_ACCEL_GRID = 1 };
 int rtk_context_set_accel(rtk_context* ctx, int32_t mode);
 int rtk_accel_in_use(rtk_context* ctx);
 
+/* How the resident scene is laid out for the kernels (diagnostics for bench.py and the profile summaries; no counterpart
+ * in the reference): out4 = { spheres, words of 32 consecutive spheres that share cy and radius and are filtered with
+ * 7 instead of 8 vector instructions per test (every small sphere of random_scene(), main.cpp:124, qualifies),
+ * 1 if the scene is LDS-resident, LDS bytes per workgroup of the render kernel }. */
+int rtk_scene_layout(rtk_context* ctx, int32_t* out4);
+
 /* Upload the flattened world.  Replaces the traversal state HittableList::hit walks
  * (HittableList.hpp:27,34): precomputes, bit-identically to the reference's own fp32 operations,
  * radius*radius (Sphere3.hpp:35) and 1/radius (Vector3.cpp:35-37 via Sphere3.hpp:54). */

@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = (
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
     "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8", "rtk_context_set_accel", "rtk_accel_in_use",
-    "rtk_render_tiles_device_noalloc",
+    "rtk_render_tiles_device_noalloc", "rtk_scene_layout",
 )
 ACCEL_LIST, ACCEL_GRID = 0, 1
 
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         l.rtk_local_tile_count.argtypes = [i32, i32, i32, i32, i32, i32]
         l.rtk_local_tile_count.restype = i64
         l.rtk_render_tiles_device.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
+        l.rtk_scene_layout.argtypes = [vp, vp]
         l.rtk_render_tiles_device_noalloc.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, C.POINTER(rtk_stats)]
         l.rtk_deinterleave_device.argtypes = [vp, vp, i64, C.POINTER(rtk_params), vp]
         l.rtk_deinterleave_u8_device.argtypes = [vp, vp, i64, C.POINTER(rtk_params), vp]
@@ -273,6 +274,11 @@ class Context:
         _check(self._l.rtk_render_tiles_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_tile_sums_ptr),
                                                C.byref(st) if want_stats else None), "rtk_render_tiles_device")
         return st.as_dict() if want_stats else None
+
+    def scene_layout(self) -> dict:
+        a = (C.c_int32 * 4)()
+        _check(self._l.rtk_scene_layout(self._h, a), "rtk_scene_layout")
+        return {"spheres": a[0], "class_words": a[1], "lds_resident": bool(a[2]), "lds_bytes_per_workgroup": a[3]}
 
     def render_tiles_device_noalloc(self, cam22, params: rtk_params, d_tile_sums_ptr: int, want_stats: bool = False):
         """rtk_render_tiles_device with the kernels' working memory in the library's static device array (rtk.h)."""

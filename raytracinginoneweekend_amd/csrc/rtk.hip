@@ -23,22 +23,25 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout: [npad] filt float4 | [npad] exact float4 (both only when LDS) | [4][kListCap][64] u16 lists |
-// (!LDS only) [4][kStageSpheres] float4 staging chunks, one per wave.
-constexpr int kLdsBytesPerSphere = 32;
+// Dynamic LDS layout: (LDS only) [filt_len] filt float4 | [npad / 32] word descriptors | [npad] exact float4 ;
+// [4][kListCap][64] u16 lists | (!LDS only) [4][kStageSpheres] float4 staging chunks, one per wave.
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {
+        const int nw = sc.npad / 32;
         float4* lf = reinterpret_cast<float4*>(p);
-        float4* le = lf + sc.npad;
-        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) lf[i] = sc.filt[i];
+        float4* lw = lf + sc.filt_len;
+        float4* le = lw + nw;
+        for (int i = threadIdx.x; i < sc.filt_len; i += blockDim.x) lf[i] = sc.filt[i];
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) lw[i] = sc.wdesc[i];
         for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) le[i] = sc.exact[i];
         it.filt = lf;
+        it.wdesc = lw;
         it.exact = le;
-        p += static_cast<size_t>(sc.npad) * kLdsBytesPerSphere;
+        p += static_cast<size_t>(sc.filt_len + nw + sc.npad) * sizeof(float4);
     } else {
         it.filt = sc.filt;
         it.exact = sc.exact;
@@ -52,8 +55,8 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     return it;
 }
 
-static size_t lds_bytes(bool lds, int npad) {
-    return (lds ? static_cast<size_t>(npad) * kLdsBytesPerSphere : kWavesPerBlock * kStageSpheres * sizeof(float4)) + kWavesPerBlock * kListCap * kWave * 2;
+static size_t lds_bytes(bool lds, const SceneDev& sc) {
+    return (lds ? static_cast<size_t>(sc.filt_len + sc.npad / 32 + sc.npad) * sizeof(float4) : kWavesPerBlock * kStageSpheres * sizeof(float4)) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
@@ -228,7 +231,8 @@ struct rtk_context {
     int blocks_per_cu[2] = {0, 0};   // [LDS]
     SceneDev scene = {};
     bool have_scene = false;
-    DevBuf filt, exact, mat0, mat1;
+    DevBuf filt, wdesc, exact, mat0, mat1;
+    int class_words = 0;     // words of 32 spheres with 8-byte class records (rtk_scene_layout)
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
     std::vector<uint2> runs_host;
     int runs_key[4] = {-1, -1, -1, -1};
@@ -251,7 +255,7 @@ struct rtk_context {
 static bool use_lds(const rtk_context* c) { return c->scene.n <= kMaxLdsSpheres; }
 static bool use_grid(const rtk_context* c) { return c->accel == RTK_ACCEL_GRID && c->grid_ok; }
 
-static size_t lds_bytes(bool lds, int npad);
+static size_t lds_bytes(bool lds, const SceneDev& sc);
 
 // Builds the uniform grid of the resident scene and uploads it.  A scene a grid cannot hold (build_grid's reasons)
 // leaves grid_ok false with the reason in rtk_last_error(): rendering then walks the list as usual.
@@ -280,7 +284,7 @@ static int upload_grid(rtk_context* c) {
     c->grid.items = static_cast<const uint32_t*>(c->g_items.p);
     c->grid.always = static_cast<const uint32_t*>(c->g_always.p);
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false, true>, kBlockThreads, lds_bytes(false, c->scene.npad)));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false, true>, kBlockThreads, lds_bytes(false, c->scene)));
     c->blocks_per_cu_grid = nb > 0 ? nb : 1;
     c->grid_ok = true;
     return RTK_OK;
@@ -362,7 +366,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->wdesc, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -394,21 +398,30 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
         return fail(RTK_ERR_BAD_ARG, "rtk_set_scene: null array");
     HIP_TRY(hipSetDevice(c->device));
     PreparedScene ps;
-    prepare_scene(s, ps);
+    const bool compact = s->n <= kMaxLdsSpheres;       // LDS-resident scenes get word descriptors and 8-byte class records
+    prepare_scene(s, ps, compact);
     const int n = ps.n, npad = ps.npad;
     const std::vector<float4>&filt = ps.filt, &exact = ps.exact, &m0 = ps.m0, &m1 = ps.m1;
     const FilterBounds fb = ps.fb;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(c->filt.reserve(sizeof(float4) * npad));
+    HIP_TRY(c->filt.reserve(sizeof(float4) * filt.size()));
     HIP_TRY(c->exact.reserve(sizeof(float4) * npad));
     HIP_TRY(c->mat0.reserve(sizeof(float4) * n));
     HIP_TRY(c->mat1.reserve(sizeof(float4) * n));
-    HIP_TRY(hipMemcpy(c->filt.p, filt.data(), sizeof(float4) * npad, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->filt.p, filt.data(), sizeof(float4) * filt.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->exact.p, exact.data(), sizeof(float4) * npad, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat0.p, m0.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat1.p, m1.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
                 static_cast<const float4*>(c->mat1.p), n, npad, fb};
+    c->scene.filt_len = static_cast<int32_t>(filt.size());
+    c->class_words = ps.class_words;
+    if (compact) {
+        if (ps.wdesc.size() != static_cast<size_t>(npad / 32)) return fail(RTK_ERR_HIP, "internal: word descriptor count");
+        HIP_TRY(c->wdesc.reserve(sizeof(float4) * ps.wdesc.size()));
+        HIP_TRY(hipMemcpy(c->wdesc.p, ps.wdesc.data(), sizeof(float4) * ps.wdesc.size(), hipMemcpyHostToDevice));
+        c->scene.wdesc = static_cast<const float4*>(c->wdesc.p);
+    }
     c->have_scene = true;
     c->h_cx.assign(s->cx, s->cx + n); c->h_cy.assign(s->cy, s->cy + n); c->h_cz.assign(s->cz, s->cz + n); c->h_radius.assign(s->radius, s->radius + n);
     c->grid_ok = false;
@@ -417,7 +430,7 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     // persistent-grid sizing for both kernel flavours at this scene size
     for (int l = 0; l < 2; ++l) {
         int nb = 0;
-        const size_t shm = lds_bytes(l == 1, npad);
+        const size_t shm = lds_bytes(l == 1, c->scene);
         if (l == 1 && !use_lds(c)) { c->blocks_per_cu[l] = 0; continue; }
         if (l == 1) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm)));
@@ -442,6 +455,17 @@ int rtk_context_set_accel(rtk_context* c, int32_t mode) {
 }
 
 int rtk_accel_in_use(rtk_context* c) { return (c && use_grid(c)) ? RTK_ACCEL_GRID : RTK_ACCEL_LIST; }
+
+int rtk_scene_layout(rtk_context* c, int32_t* out4) {
+    if (!c || !out4) return fail(RTK_ERR_BAD_ARG, "rtk_scene_layout: null argument");
+    if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scene_layout: call rtk_set_scene first");
+    const bool lds = use_lds(c) && !use_grid(c);
+    out4[0] = c->scene.n;
+    out4[1] = c->class_words;
+    out4[2] = lds ? 1 : 0;
+    out4[3] = static_cast<int32_t>(lds_bytes(lds, c->scene) + sizeof(CameraDev) + 8);     // dynamic + the kernels' static LDS (camera copy)
+    return RTK_OK;
+}
 
 static int norm_tiles(const rtk_params* p, int& tw, int& th) {
     tw = p->tile_w;
@@ -564,7 +588,7 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
 
     const bool accel = use_grid(c);
     const bool lds = use_lds(c) && !accel;
-    const size_t shm = lds_bytes(lds, c->scene.npad);
+    const size_t shm = lds_bytes(lds, c->scene);
     A.grid = c->grid;
     int64_t grid = static_cast<int64_t>(c->n_cu) * (accel ? c->blocks_per_cu_grid : c->blocks_per_cu[lds ? 1 : 0]);
     const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -728,7 +752,7 @@ int rtk_intersect_batch_device(rtk_context* c, const float* d_rays, size_t n, fl
     HIP_TRY(hipSetDevice(c->device));
     const bool accel = use_grid(c);
     const bool lds = use_lds(c) && !accel;
-    const size_t shm = lds_bytes(lds, c->scene.npad);
+    const size_t shm = lds_bytes(lds, c->scene);
     size_t grid = (n + kBlockThreads - 1) / kBlockThreads;
     const int bpc = accel ? c->blocks_per_cu_grid : c->blocks_per_cu[lds ? 1 : 0];
     const size_t cap = static_cast<size_t>(c->n_cu) * (bpc > 0 ? bpc : 1);

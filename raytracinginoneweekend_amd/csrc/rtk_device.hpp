@@ -116,13 +116,21 @@ struct FilterBounds {
 };
 
 struct SceneDev {
-    const float4* filt;   // [npad] cx, cy, cz, r^2 (1+k): filter operands; pads never pass
+    // Filter operands, one record block per WORD of 32 consecutive list entries (list order is kept: the exact stage's
+    // tie rule depends on it).  A general word holds 32 float4 (cx, cy, cz, r^2 (1+k)); a CLASS word — all 32 spheres
+    // filterable with bit-identical cy and radius, which is what every small sphere of the reference's random_scene()
+    // is (main.cpp:124: centre (a + .9 rand, 0.2, b + .9 rand), radius 0.2) — holds 16 float4 = 32 x (cx, cz), and its
+    // shared cy and r^2 (1+k) sit in the word's descriptor: two of the eight FMAs of a test become per-ray constants.
+    // Pads never pass.  wdesc == nullptr: every word is general at offset 32 w (scenes streamed through LDS chunks).
+    const float4* filt;   // [filt_len]
     const float4* exact;  // [npad] cx, cy, cz, r*r  (fl(r*r), Sphere3.hpp:35)
     const float4* mat0;   // [n] colour r, g, b, roughness
     const float4* mat1;   // [n] metallic, ior, type (int bits), 1/radius (fl(1/r), Vector3.cpp:36)
     int32_t n;
     int32_t npad;         // n rounded up to a multiple of 32
     FilterBounds fb;
+    const float4* wdesc = nullptr;   // [npad / 32] x: offset into filt (int bits), y: 1 = class word (int bits), z: cy, w: r^2 (1+k)
+    int32_t filt_len = 0;            // float4 entries of filt
 };
 
 struct CameraDev {

@@ -11,9 +11,11 @@ namespace rtk {
 // Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
 //
 // Stage 1 (filter, all spheres, pure VALU): a conservative sign test — is the sphere's centre, projected on the plane
-// perpendicular to the ray, within r of the ray (9 VALU instructions per sphere) — every lane of the wavefront testing
-// the same sphere (operands broadcast from LDS; scenes too large for LDS stream through a wave-private LDS chunk).
-// The sign bits are funnel-shifted into one mask word per 32 spheres.
+// perpendicular to the ray, within r of the ray — every lane of the wavefront testing the same sphere (operands
+// broadcast from LDS; scenes too large for LDS stream through a wave-private LDS chunk).  The plane's basis has
+// e1.y == 0, so a test is 7 FMAs + one funnel shift (8 VALU); words of 32 spheres that share cy and radius
+// (SceneDev::wdesc) fold cy into a per-ray constant: 6 FMAs + the shift (7 VALU).  The sign bits are funnel-shifted
+// into one mask word per 32 spheres.
 // Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
 // Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
@@ -66,6 +68,7 @@ struct GridDev {
 template <bool LDS>
 struct Intersector {
     const float4* filt;    // LDS or global
+    const float4* wdesc = nullptr;   // LDS (with LDS == true) or null: word descriptors, SceneDev::wdesc
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
     float4* stage = nullptr;     // !LDS: this wave's LDS chunk of kStageSpheres filter operands
@@ -95,16 +98,23 @@ struct Intersector {
         cnt = 0;
     }
 
-    // Per-ray operands of the filter: the shrunk basis (e1, e2) of the plane perpendicular to the ray and -o.e.
+    // Per-ray operands of the filter: the shrunk basis (e1, e2) of the plane perpendicular to the ray, e1.y == 0, and -o.e.
     struct FilterRay {
-        float e1x, e1y, e1z, ns1, e2x, e2y, e2z, ns2;
+        float e1x, e1z, ns1, e2x, e2y, e2z, ns2;
     };
 
     // One ray-sphere filter test; shifts the result bit into `m` (1 = candidate).
     static __device__ __forceinline__ void filter_one(const FilterRay& f, float sx, float sy, float sz, float sw, uint32_t& m) {
-        const float p1 = fmaf(sz, f.e1z, fmaf(sy, f.e1y, fmaf(sx, f.e1x, f.ns1)));
+        const float p1 = fmaf(sz, f.e1z, fmaf(sx, f.e1x, f.ns1));
         const float p2 = fmaf(sz, f.e2z, fmaf(sy, f.e2y, fmaf(sx, f.e2x, f.ns2)));
         const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
+    }
+    // The same for a sphere of a class word: k2 = cy e2.y - o.e2 and nr2 = -r^2 (1+k) are the word's per-ray constants.
+    static __device__ __forceinline__ void filter_class(const FilterRay& f, float k2, float nr2, float sx, float sz, uint32_t& m) {
+        const float p1 = fmaf(sz, f.e1z, fmaf(sx, f.e1x, f.ns1));
+        const float p2 = fmaf(sz, f.e2z, fmaf(sx, f.e2x, k2));
+        const float dd = fmaf(p2, p2, fmaf(p1, p1, nr2));
         m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
     }
 
@@ -115,28 +125,30 @@ struct Intersector {
         // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
         // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
         const float big = 0x1p30f;
-        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
         FilterRay f;
         const float inv_len = __builtin_amdgcn_rsqf(a);
-        // Orthonormal basis (e1, e2) of the plane perpendicular to the ray (Duff et al. 2017, branch-free);
-        // a sphere can only be hit if its centre, projected on that plane, lies within r of the ray.
-        // The projected distances are shrunk by g < 1 so that everything the reference's own rounding could
-        // still accept (E) and this filter's evaluation error (dp) stay inside r.
+        // Orthonormal basis (e1, e2) of the plane perpendicular to the ray with e1 horizontal:
+        //   e1 = (dz, 0, -dx) / h,  e2 = d x e1 = (-dx dy / h, h, -dy dz / h),  h = sqrt(dx^2 + dz^2)   (d = unit direction).
+        // No cancellation anywhere: every component is a product of rounded values, so e1 and e2 are orthogonal to d to
+        // a few ulp whatever h is; only a ray within 2^-20 of the y axis (h^2 < 2^-40) has no usable horizontal
+        // direction and tests every sphere.  A sphere can only be hit if its centre, projected on that plane, lies
+        // within r of the ray.  The projected distances are shrunk by g < 1 so that everything the reference's own
+        // rounding could still accept (E) and this filter's evaluation error (dp) stay inside r.
         const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
-        const float sg = copysignf(1.0f, dz);
-        const float aa = -__builtin_amdgcn_rcpf(sg + dz);
-        const float bb = dx * dy * aa;
-        const float u1x = fmaf(sg * dx, dx * aa, 1.0f), u1y = sg * bb, u1z = -sg * dx;     // unshrunk basis
-        const float u2x = bb, u2y = fmaf(dy, dy * aa, sg), u2z = -dy;
+        const float h2 = fmaf(dx, dx, dz * dz);
+        const float inv_h = __builtin_amdgcn_rsqf(h2);
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f) && (h2 > 0x1p-40f);
+        const float u1x = dz * inv_h, u1z = -dx * inv_h;                     // unshrunk basis
+        const float u2x = -dy * (dx * inv_h), u2y = h2 * inv_h, u2z = -dy * (dz * inv_h);
         {
             const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
             const float M = o_len + fb.c_max;
             const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
             const float dp = 0x1p-19f * M;
             const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
-            f.e1x = g * u1x; f.e1y = g * u1y; f.e1z = g * u1z;
+            f.e1x = g * u1x; f.e1z = g * u1z;
             f.e2x = g * u2x; f.e2y = g * u2y; f.e2z = g * u2z;
-            f.ns1 = -fmaf(r.o.z, f.e1z, fmaf(r.o.y, f.e1y, r.o.x * f.e1x));
+            f.ns1 = -fmaf(r.o.z, f.e1z, r.o.x * f.e1x);
             f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
         }
         RTK_STAT(lane, closest_hit_calls);
@@ -173,8 +185,8 @@ struct Intersector {
             return active ? cand : 0u;
         };
 
-        // filter + compaction over `count` consecutive spheres starting at list index `base`; load(i) yields the
-        // operands of sphere base + i
+        // filter + compaction over `count` consecutive spheres starting at list index `base`, all general words;
+        // load(i) yields the operands of sphere base + i
         auto scan = [&](auto&& load, int base, int count) {
             const int full = count >> 5, rem = count & 31;
             for (int w = 0; w < full; ++w) {
@@ -200,6 +212,47 @@ struct Intersector {
                 }
                 m <<= (32 - rem);
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+            }
+        };
+        // the same over the LDS-resident scene, word by word through the descriptors (class words: 16 float4 = 32 x (cx, cz))
+        auto scan_words = [&]() {
+            const int full = n >> 5, rem = n & 31;
+            for (int w = 0; w < full; ++w) {
+                const float4 wd = wdesc[w];
+                const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
+                const int kind = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y));
+                const float4* q = filt + off;
+                uint32_t m = 0;
+                if (kind != 0) {
+                    const float k2 = fmaf(wd.z, f.e2y, f.ns2), nr2 = -wd.w;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float4 s = q[i];
+                        filter_class(f, k2, nr2, s.x, s.y, m);
+                        filter_class(f, k2, nr2, s.z, s.w, m);
+                    }
+                    RTK_STAT(lane, class_words);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const float4 s = q[i];
+                        filter_one(f, s.x, s.y, s.z, s.w, m);
+                    }
+                }
+                RTK_STAT(lane, filter_words);
+                emit(w * 32, to_cand(m, 0xFFFFFFFFu));
+            }
+            if (rem) {
+                const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wdesc[full].x));      // the last, partial word is always general
+                const float4* q = filt + off;
+                uint32_t m = 0;
+#pragma unroll 4
+                for (int i = 0; i < rem; ++i) {
+                    const float4 s = q[i];
+                    filter_one(f, s.x, s.y, s.z, s.w, m);
+                }
+                m <<= (32 - rem);
+                emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
         if (!LDS) {
@@ -237,6 +290,8 @@ struct Intersector {
                 }
                 scan([&](int i) { return stage[i]; }, base, count);
             }
+        } else if (wdesc) {
+            scan_words();
         } else {
             scan([&](int i) { return filt[i]; }, 0, n);
         }

@@ -17,6 +17,8 @@ namespace rtk {
 
 struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
+    std::vector<float4> wdesc;       // compact layout only (SceneDev::wdesc); empty = every word general at offset 32 w
+    int class_words = 0;
     std::vector<char> filterable;    // per sphere: finite, moderate, not an outlier (the filter / the grid may cull it)
     FilterBounds fb;
     int n = 0, npad = 0;
@@ -24,7 +26,8 @@ struct PreparedScene {
 
 // Precomputes, bit-identically to the reference's own fp32 operations, radius*radius (Sphere3.hpp:35) and
 // 1/radius (Vector3.cpp:35-37 via Sphere3.hpp:54); classifies the spheres the filter may reject and bounds them.
-inline void prepare_scene(const rtk_scene* s, PreparedScene& out) {
+// `compact`: words of 32 spheres that share cy and radius get 8-byte records (SceneDev); without it every word is general.
+inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact = false) {
     const int n = s->n, npad = (n + 31) / 32 * 32;
     out.n = n;
     out.npad = npad;
@@ -86,6 +89,32 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out) {
     }
     out.fb = fb;
     out.filterable = filterable;
+    out.wdesc.clear();
+    out.class_words = 0;
+    if (compact) {
+        // One descriptor per word.  Class word: 32 filterable spheres with bit-identical cy and widened r^2.
+        auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };
+        std::vector<float4> packed;
+        packed.reserve(npad);
+        for (int w = 0; w * 32 < npad; ++w) {
+            const int base = w * 32;
+            bool cls = base + 32 <= n;
+            for (int i = base; cls && i < base + 32; ++i)
+                cls = filterable[i] && same_bits(filt[i].y, filt[base].y) && same_bits(filt[i].w, filt[base].w);
+            const int32_t off = static_cast<int32_t>(packed.size()), kind = cls ? 1 : 0;
+            float off_f, kind_f;
+            std::memcpy(&off_f, &off, 4);
+            std::memcpy(&kind_f, &kind, 4);
+            out.wdesc.push_back(make_float4(off_f, kind_f, cls ? filt[base].y : 0.0f, cls ? filt[base].w : 0.0f));
+            if (cls) {
+                for (int i = base; i < base + 32; i += 2) packed.push_back(make_float4(filt[i].x, filt[i].z, filt[i + 1].x, filt[i + 1].z));
+                ++out.class_words;
+            } else {
+                for (int i = base; i < base + 32; ++i) packed.push_back(filt[i]);
+            }
+        }
+        filt.swap(packed);
+    }
 }
 
 // ---- uniform grid (GridDev in rtk_device.hpp) -----------------------------------------------------

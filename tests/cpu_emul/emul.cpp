@@ -47,9 +47,10 @@ static void run_lanes(F&& body) {
 using namespace rtk;
 
 struct Emul {
-    PreparedScene ps;
+    PreparedScene ps;          // as the path the scene runs on gets it (compact layout on the LDS-resident path)
     SceneDev dev;
     GridHost grid;
+    bool compact = false;
 };
 
 // Which instantiation a scene runs on: the GPU takes Intersector<true> (operands straight from the LDS copy) up to
@@ -60,12 +61,13 @@ struct Emul {
 #define EMUL_FORCE_STAGED (RTK_LANES == 64)
 #endif
 static bool g_force_staged = EMUL_FORCE_STAGED;
-static bool use_lds_path(const Emul& e) { return !g_force_staged && e.ps.n <= kMaxLdsSpheres; }
+static bool use_lds_path(const Emul& e) { return e.compact; }
 
 template <bool LDS>
 static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
     Intersector<LDS> it;
     it.filt = e.ps.filt.data();
+    if (LDS) it.wdesc = e.ps.wdesc.data();
     it.exact = e.ps.exact.data();
     it.list = list;
     it.fb = e.ps.fb;
@@ -80,8 +82,11 @@ extern "C" {
 
 void* emul_create(const rtk_scene* s) {
     Emul* e = new Emul();
-    prepare_scene(s, e->ps);
+    e->compact = !g_force_staged && s->n <= kMaxLdsSpheres;
+    prepare_scene(s, e->ps, e->compact);
     e->dev = {e->ps.filt.data(), e->ps.exact.data(), e->ps.m0.data(), e->ps.m1.data(), e->ps.n, e->ps.npad, e->ps.fb};
+    e->dev.filt_len = static_cast<int32_t>(e->ps.filt.size());
+    if (e->compact) e->dev.wdesc = e->ps.wdesc.data();
     build_grid(s, e->ps, e->grid);
     e->grid.dev.cell_start = e->grid.cell_start.data();
     e->grid.dev.items = e->grid.items.data();
@@ -100,6 +105,8 @@ void emul_grid_info(void* h, int64_t* info8) {
     info8[8] = static_cast<int64_t>(g.dev.znx) * g.dev.zny * g.dev.znz;
 }
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
+// words of the scene that got 8-byte class records (0 when the scene runs on the staged path)
+int emul_class_words(void* h) { return static_cast<Emul*>(h)->ps.class_words; }
 
 void emul_set_ulp_noise(int k) { rtk_shim::ulp_noise = k; }
 void emul_force_staged(int on) { g_force_staged = on != 0; }
@@ -108,7 +115,7 @@ void emul_force_staged(int on) { g_force_staged = on != 0; }
 void emul_scene_info(void* h, float* bounds3, uint8_t* filterable) {
     const Emul& e = *static_cast<Emul*>(h);
     bounds3[0] = e.ps.fb.c_max; bounds3[1] = e.ps.fb.r_max2; bounds3[2] = e.ps.fb.r_min;
-    for (int i = 0; i < e.ps.n; ++i) filterable[i] = std::isinf(e.ps.filt[i].w) ? 0 : 1;
+    for (int i = 0; i < e.ps.n; ++i) filterable[i] = e.ps.filterable[i] ? 1 : 0;
 }
 
 // Intersector::closest_hit per ray; `flags` (optional, [n][scene size]) receives the filter's candidate flags.

@@ -86,7 +86,7 @@ namespace rtk_shim {
 struct WaveStats {
     unsigned long long closest_hit_calls, filter_words, compact_iters, early_flushes, flush_iters;
     unsigned long long pass_refill_block, pass_assign_iters, pass_start_block, pass_sky_block, pass_hit_block;
-    unsigned long long pass_lambert, pass_metal, pass_glass, pass_unit_flush_block, packet_draws;
+    unsigned long long pass_lambert, pass_metal, pass_glass, pass_unit_flush_block, packet_draws, class_words;
 };
 extern thread_local WaveStats wave_stats;
 }

@@ -13,7 +13,7 @@ _libs = {}
 
 STAT_FIELDS = ("closest_hit_calls", "filter_words", "compact_iters", "early_flushes", "flush_iters", "pass_refill_block",
                "pass_assign_iters", "pass_start_block", "pass_sky_block", "pass_hit_block", "pass_lambert", "pass_metal",
-               "pass_glass", "pass_unit_flush_block", "packet_draws")
+               "pass_glass", "pass_unit_flush_block", "packet_draws", "class_words")
 
 
 def lib(lanes=1):
@@ -25,6 +25,7 @@ def lib(lanes=1):
         l.emul_create.restype = vp
         l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]
         l.emul_destroy.argtypes = [vp]
+        l.emul_class_words.argtypes = [vp]
         l.emul_scene_info.argtypes = [vp, vp, vp]
         l.emul_intersect.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int]
         l.emul_grid_info.argtypes = [vp, vp]
@@ -72,6 +73,10 @@ class Emul:
         f = np.zeros(self.n, np.uint8)
         self._l.emul_scene_info(self._h, b.ctypes.data, f.ctypes.data)
         return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2])}, f
+
+    def class_words(self) -> int:
+        """Words of 32 spheres that got 8-byte class records (shared cy and radius); 0 on the staged path."""
+        return int(self._l.emul_class_words(self._h))
 
     def grid_info(self):
         a = np.zeros(9, np.int64)

@@ -208,3 +208,76 @@ def test_unusual_ranges(stock_scene_golden, t_min, t_max):
     z = load_golden("rays_stock.npz")
     rays = np.concatenate([z["primary_rays"][:1500], z["inside_rays"][:800], z["degenerate_rays"]])
     check(stock_scene_golden, rays, t_min, t_max, noises=(0,))
+
+
+# ---- class words (SceneDev::wdesc) and the horizontal basis e1 = (dz, 0, -dx) / h ------------------------------------
+def _class_scene(rng, n, y_groups, offset=(0.0, 0.0, 0.0), scale=1.0):
+    """`n` spheres in list order: consecutive groups take their (cy, radius) from `y_groups` (None = random per sphere)."""
+    cx = rng.uniform(-11, 11, n); cz = rng.uniform(-11, 11, n)
+    cy = rng.uniform(0.1, 1.5, n); rad = rng.uniform(0.1, 0.5, n)
+    per = max(1, n // len(y_groups))
+    for g, yr in enumerate(y_groups):
+        if yr is not None:
+            sl = slice(g * per, n if g == len(y_groups) - 1 else (g + 1) * per)
+            cy[sl] = yr[0]; rad[sl] = yr[1]
+    s = {"cx": cx * scale + offset[0], "cy": cy * scale + offset[1], "cz": cz * scale + offset[2], "radius": rad * scale}
+    s = {k: v.astype(np.float32) for k, v in s.items()}
+    for k, v in (("mat_r", 0.5), ("mat_g", 0.5), ("mat_b", 0.5), ("roughness", 1.0), ("metallic", 0.0), ("ior", 1.5)):
+        s[k] = np.full(n, v, np.float32)
+    s["mat_type"] = np.ones(n, np.int32)
+    return s
+
+
+def test_stock_scene_has_fourteen_class_words(stock_scene_golden):
+    """random_scene(): ground, 480 small spheres at y = 0.2 with r = 0.2, three big ones -> words 1..14 of 32 are class words."""
+    e = Emul(stock_scene_golden)
+    assert e.class_words() == 14
+
+
+@pytest.mark.parametrize("groups,n,want_words", [([(0.2, 0.2)], 96, 3), ([(0.2, 0.2), None, (1.0, 0.3)], 288, 6), ([None], 64, 0),
+                                                 ([(0.2, 0.2)], 40, 1), ([(-0.0, 0.25), (0.0, 0.25)], 64, 2)])
+def test_class_words_parity_and_conservativeness(groups, n, want_words):
+    rng = np.random.default_rng(n + len(groups))
+    s = _class_scene(rng, n, groups)
+    assert Emul(s).class_words() == want_words
+    m = 3000
+    rays = np.concatenate([np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32),
+                           tangent_rays(rng, s, 1500, 0.5, 300, 1e-5)])
+    check(s, rays)
+
+
+def test_mixed_sign_zero_y_is_not_one_class():
+    """cy = -0.0 and +0.0 differ bitwise: a word mixing them stays general (harmless either way; pinned so it is a decision)."""
+    rng = np.random.default_rng(3)
+    s = _class_scene(rng, 32, [(0.0, 0.25)])
+    s["cy"][5] = np.float32(-0.0)
+    assert Emul(s).class_words() == 0
+
+
+@pytest.mark.parametrize("tilt", [0.0, 1e-12, 1e-7, 1e-6, 3e-6, 1e-4, 1e-2])
+def test_rays_along_the_y_axis(stock_scene_golden, tilt):
+    """The filter's basis needs a horizontal direction: rays within 2^-20 of the y axis test every sphere instead, rays
+    just outside that cone use a basis built from a tiny h = |(dx, dz)| — both must stay exact and conservative."""
+    rng = np.random.default_rng(int(tilt * 1e13) + 1)
+    n = 1500
+    o = np.stack([rng.uniform(-11, 11, n), rng.uniform(0.5, 6.0, n), rng.uniform(-11, 11, n)], 1)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    d = np.stack([tilt * np.cos(phi), -np.ones(n), tilt * np.sin(phi)], 1) * rng.uniform(0.3, 3.0, (n, 1))
+    d[::2] *= -1.0                                           # half of them point up (hit nothing or a sphere above)
+    # aim a third of them at the silhouette of a small sphere from straight above
+    k = rng.integers(1, 481, n // 3)
+    c = np.stack([stock_scene_golden["cx"][k], stock_scene_golden["cy"][k], stock_scene_golden["cz"][k]], 1)
+    psi = rng.uniform(0, 2 * np.pi, n // 3)
+    o[: n // 3] = c + np.stack([0.2 * (1 + rng.uniform(-1e-5, 1e-5, n // 3)) * np.cos(psi), np.full(n // 3, 3.0), 0.2 * np.sin(psi)], 1)
+    d[: n // 3, 1] = -np.abs(d[: n // 3, 1])
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    check(stock_scene_golden, rays)
+
+
+def test_translated_class_scene_far_from_the_origin():
+    rng = np.random.default_rng(11)
+    s = _class_scene(rng, 128, [(0.2, 0.2)], offset=(3000.0, -200.0, 1500.0))
+    m = 2000
+    o = rng.uniform(-12, 12, (m, 3)) + np.array([3000.0, -200.0, 1500.0])
+    rays = np.concatenate([np.concatenate([o, rng.normal(size=(m, 3))], 1).astype(np.float32), tangent_rays(rng, s, 1500, 0.5, 3000, 1e-5)])
+    check(s, rays)
