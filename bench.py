@@ -42,7 +42,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-KERNEL_TAG = "r02-a (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius; decreasing run schedule)"   # bump when the kernel changes
+KERNEL_TAG = "r02-b (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius, candidate mask words kept in LDS; decreasing run schedule)"   # bump when the kernel changes
 
 
 def cpu_baseline():

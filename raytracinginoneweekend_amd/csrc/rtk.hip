@@ -23,8 +23,9 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout: (LDS only) [filt_len] filt float4 | [npad / 32] word descriptors | [npad] exact float4 ;
-// [4][kListCap][64] u16 lists | (!LDS only) [4][kStageSpheres] float4 staging chunks, one per wave.
+// Dynamic LDS layout.  LDS-resident scene: [filt_len] filt float4 | [npad / 32] word descriptors | [npad] exact float4 |
+// [4 waves][npad / 32][64] u32 candidate mask words.  Streamed scene: [4][kListCap][64] u16 candidate lists |
+// [4][kStageSpheres] float4 staging chunks, one per wave.
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
@@ -42,12 +43,14 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
         it.wdesc = lw;
         it.exact = le;
         p += static_cast<size_t>(sc.filt_len + nw + sc.npad) * sizeof(float4);
+        it.masks = reinterpret_cast<uint32_t*>(p) + wave * (nw * kWave);
+        it.list = nullptr;
     } else {
         it.filt = sc.filt;
         it.exact = sc.exact;
+        it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
+        it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
     }
-    it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
-    if (!LDS) it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
     it.n = sc.n;
     it.fb = sc.fb;
     it.lane = lane;
@@ -56,7 +59,8 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 }
 
 static size_t lds_bytes(bool lds, const SceneDev& sc) {
-    return (lds ? static_cast<size_t>(sc.filt_len + sc.npad / 32 + sc.npad) * sizeof(float4) : kWavesPerBlock * kStageSpheres * sizeof(float4)) + kWavesPerBlock * kListCap * kWave * 2;
+    return lds ? static_cast<size_t>(sc.filt_len + sc.npad / 32 + sc.npad) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
+               : kWavesPerBlock * kStageSpheres * sizeof(float4) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.

@@ -16,8 +16,10 @@ namespace rtk {
 // e1.y == 0, so a test is 7 FMAs + one funnel shift (8 VALU); words of 32 spheres that share cy and radius
 // (SceneDev::wdesc) fold cy into a per-ray constant: 6 FMAs + the shift (7 VALU).  The sign bits are funnel-shifted
 // into one mask word per 32 spheres.
-// Stage 2 (compaction): candidate bits -> per-lane list in LDS, ascending list index.
-// Stage 3 (exact): each lane walks its own list with the reference's arithmetic and range tests
+// Stage 2 (candidates): LDS-resident scenes keep the mask words themselves — a lane stores each non-zero word in its LDS
+// slot and notes the word in a register bitmap (no loop, no vote per word); streamed scenes compact the bits into a
+// per-lane list of 16-bit indices (a full list triggers an early exact pass).  Ascending list index either way.
+// Stage 3 (exact): each lane walks its own candidates with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
 // Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
@@ -70,7 +72,8 @@ struct Intersector {
     const float4* filt;    // LDS or global
     const float4* wdesc = nullptr;   // LDS (with LDS == true) or null: word descriptors, SceneDev::wdesc
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
-    uint16_t* list;        // this wave's candidate list in LDS: [kListCap][64]
+    uint16_t* list;        // !LDS: this wave's candidate list in LDS: [kListCap][64]
+    uint32_t* masks = nullptr;   // LDS: this wave's candidate mask words in LDS: [npad / 32][64]
     float4* stage = nullptr;     // !LDS: this wave's LDS chunk of kStageSpheres filter operands
     FilterBounds fb;
     int n;
@@ -214,9 +217,18 @@ struct Intersector {
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
-        // the same over the LDS-resident scene, word by word through the descriptors (class words: 16 float4 = 32 x (cx, cz))
+        // The LDS-resident scene, word by word through the descriptors (class words: 16 float4 = 32 x (cx, cz)).  A lane
+        // keeps every non-zero mask word in its LDS slot and the set of those words in `nz` (bit 31 - w: at most 32
+        // words, kMaxLdsSpheres = 1024); then it walks its own candidates in ascending list order.
         auto scan_words = [&]() {
             const int full = n >> 5, rem = n & 31;
+            uint32_t nz = 0;
+            auto keep = [&](int w, uint32_t m) {
+                if (m != 0) {
+                    masks[w * kWave + lane] = m;
+                    nz |= 0x80000000u >> w;
+                }
+            };
             for (int w = 0; w < full; ++w) {
                 const float4 wd = wdesc[w];
                 const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
@@ -240,7 +252,7 @@ struct Intersector {
                     }
                 }
                 RTK_STAT(lane, filter_words);
-                emit(w * 32, to_cand(m, 0xFFFFFFFFu));
+                keep(w, m);
             }
             if (rem) {
                 const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wdesc[full].x));      // the last, partial word is always general
@@ -251,8 +263,48 @@ struct Intersector {
                     const float4 s = q[i];
                     filter_one(f, s.x, s.y, s.z, s.w, m);
                 }
-                m <<= (32 - rem);
-                emit(full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
+                keep(full, m << (32 - rem));
+            }
+            // lanes whose ray the filter cannot judge test every sphere (rare: one vote per ray, outside the word loop)
+            if (wave_any(active && !safe)) {
+                if (!safe) {
+                    for (int w = 0; w < full; ++w) masks[w * kWave + lane] = 0xFFFFFFFFu;
+                    if (rem) masks[full * kWave + lane] = 0xFFFFFFFFu << (32 - rem);
+                    const int words = full + (rem ? 1 : 0);
+                    nz = words >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> words);
+                }
+            }
+            if (!active) nz = 0;
+#ifdef RTK_HOST_EMULATION
+            if (dbg_flags)
+                for (int w = 0; w < full + (rem ? 1 : 0); ++w)
+                    if (nz & (0x80000000u >> w))
+                        for (int b = 0; b < 32; ++b)
+                            if (masks[w * kWave + lane] & (0x80000000u >> b)) dbg_flags[w * 32 + b] = 1;
+#endif
+            // exact stage: every lane pops its own candidates, lowest list index first
+            uint32_t m = 0;
+            int wb = 0;
+            while (wave_any((m | nz) != 0)) {
+                RTK_STAT(lane, flush_iters);
+                if (m == 0 && nz != 0) {          // this lane's next non-empty word
+                    const int w = __clz(static_cast<int>(nz));
+                    nz &= ~(0x80000000u >> w);
+                    m = masks[w * kWave + lane];
+                    wb = w << 5;
+                }
+                if (m != 0) {
+                    const int pos = __clz(static_cast<int>(m));
+                    m &= ~(0x80000000u >> pos);
+                    const int j = wb + pos;
+                    const float4 s = exact[j];
+                    float root;
+                    if (sphere_root_exact(r, a, s, t_min, closest, root)) {
+                        closest = root;
+                        best = j;
+                    }
+                    ++n_exact;
+                }
             }
         };
         if (!LDS) {
@@ -290,12 +342,10 @@ struct Intersector {
                 }
                 scan([&](int i) { return stage[i]; }, base, count);
             }
-        } else if (wdesc) {
-            scan_words();
+            flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         } else {
-            scan([&](int i) { return filt[i]; }, 0, n);
+            scan_words();
         }
-        flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         t_out = closest;
         idx_out = best;
     }

@@ -64,10 +64,13 @@ static bool g_force_staged = EMUL_FORCE_STAGED;
 static bool use_lds_path(const Emul& e) { return e.compact; }
 
 template <bool LDS>
-static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr) {
+static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr, uint32_t* masks = nullptr) {
     Intersector<LDS> it;
     it.filt = e.ps.filt.data();
-    if (LDS) it.wdesc = e.ps.wdesc.data();
+    if (LDS) {
+        it.wdesc = e.ps.wdesc.data();
+        it.masks = masks;
+    }
     it.exact = e.ps.exact.data();
     it.list = list;
     it.fb = e.ps.fb;
@@ -126,6 +129,7 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
     rtk_shim::ulp_noise = ulp_noise;
     std::vector<uint16_t> list(kListCap * kWave);
     std::vector<float4> stage(kStageSpheres);
+    std::vector<uint32_t> masks(static_cast<size_t>(e.ps.npad / 32) * kWave);       // the wave's candidate mask words (LDS path)
     std::vector<uint32_t> ne_lane(kWave, 0);
     uint64_t total = 0;
     const bool lds = use_lds_path(e);
@@ -143,7 +147,7 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
             int idx;
             uint32_t ne = 0;
             if (lds) {
-                const Intersector<true> it = make_isect<true>(e, list.data(), dbg, lane);
+                const Intersector<true> it = make_isect<true>(e, list.data(), dbg, lane, nullptr, masks.data());
                 if (accel) it.closest_hit_grid(e.grid.dev, r, active, t_min, t_max, tt, idx, ne);
                 else it.closest_hit(r, active, t_min, t_max, tt, idx, ne);
             } else {
@@ -243,9 +247,10 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
         pool.emplace_back([&] {
             std::vector<uint16_t> list(kListCap * kWave);
             std::vector<float4> stage(kStageSpheres);
+            std::vector<uint32_t> masks(static_cast<size_t>(e.ps.npad / 32) * kWave);
             run_lanes([&](int lane) {
                 if (lds) {
-                    const Intersector<true> it = make_isect<true>(e, list.data(), nullptr, lane);
+                    const Intersector<true> it = make_isect<true>(e, list.data(), nullptr, lane, nullptr, masks.data());
                     if (accel) render_wave<true, true>(A, it, &A.cam);
                     else render_wave<true, false>(A, it, &A.cam);
                 } else {
