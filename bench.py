@@ -42,7 +42,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-KERNEL_TAG = "r02-b (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius, candidate mask words kept in LDS; decreasing run schedule)"   # bump when the kernel changes
+KERNEL_TAG = "r02-c (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius, candidate mask words kept in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
 
 
 def cpu_baseline():
@@ -207,7 +207,8 @@ def main():
                                   "%.2f-instruction fp32 filter per test plus ~2 exact reference tests per ray; executed-fp32 fraction from counters: profiles/*_summary.md" % filt_valu,
                          "filter_valu_per_test": filt_valu, "class_words": lay["class_words"], "lds_bytes_per_workgroup": lay["lds_bytes_per_workgroup"],
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays)},
+                         "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays),
+                         "drain_frac_last_frame": st.get("drain_frac")},
         }
         if args.accel == "grid":
             # the 17-flop-per-test model prices the list walk; with a grid the useful figure is tests per ray

@@ -81,8 +81,9 @@ typedef struct rtk_params {
     int32_t world_size;   /* ... of the row-major grid of tile_w x tile_h pixel tiles */
     int32_t tile_w;       /* tile_w * tile_h must be 64 (one wavefront of pixels); 0,0 -> 8 x 8 */
     int32_t tile_h;
-    int32_t run_len;      /* > 0: a lane sums runs of this many samples in fp32 before one fixed-point add;
-                           * 0: the default decreasing partition, see rtk_run_schedule */
+    int32_t run_len;      /* how a pixel's samples are cut into units of work; the IMAGE does not depend on it (every sample
+                           * becomes 32.32 fixed point before it is summed).  0: the default decreasing partition, see
+                           * rtk_run_schedule; > 0: runs of this many samples; < 0: decreasing with k = -run_len */
     int32_t sample_offset; /* index of the first sample (default 0): a frame can be rendered progressively, in batches
                            * [offset, offset + spp) whose sums the caller adds; batches never share RNG counters */
 } rtk_params;
@@ -100,6 +101,12 @@ typedef struct rtk_stats {
     float total_ms;            /* clear + render + finalise of the last frame (only from a call given `stats`) */
     uint32_t frames;           /* frames rendered since the last rtk_reset_stats */
     uint32_t frames_timed;     /* frames whose kernel time is in kernel_ms (at most 256 are kept) */
+    uint64_t max_wave_passes;  /* most passes any one wavefront made in one frame: the kernel's critical path
+                                * (lane_slots / 64 / waves is the mean; their ratio is the load balance across waves) */
+    uint64_t waves;            /* wavefronts of the last render kernel launch */
+    float drain_frac;          /* last frame: share of the kernel's duration that passed after the FIRST wavefront ran out of work
+                                * (the tail during which the GPU empties; fixed 100 MHz device clock) */
+    float reserved_;
 } rtk_stats;
 
 typedef struct rtk_context rtk_context;
@@ -149,11 +156,11 @@ int rtk_set_scene(rtk_context* ctx, const rtk_scene* scene);
 int64_t rtk_local_tile_count(int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, int32_t rank,
                              int32_t world_size);
 
-/* The partition of the spp samples of a pixel into runs that a render of (spp, width, height, run_len) uses:
- * n pairs (first sample, length) into out_pairs (2 * cap uint32), returns n (out_pairs may be NULL to query n).
- * Pure host function (no device needed).  The partition never depends on rank or world_size, which is what
- * keeps images bit-identical across GPU counts; no counterpart in the reference (its sample loop is serial,
- * main.cpp:68). */
+/* The partition of the spp samples of a pixel into runs that a rank owning width x height pixels uses for
+ * (spp, run_len): n pairs (first sample, length) into out_pairs (2 * cap uint32), returns n (out_pairs may be NULL to
+ * query n).  Pure host function (no device needed).  A rank of a sharded frame sizes the partition for ITS pixel count
+ * (finer when it owns fewer pixels, for load balance); images stay bit-identical across GPU counts because samples are
+ * summed as integers, whatever the partition.  No counterpart in the reference (its sample loop is serial, main.cpp:68). */
 int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len, uint32_t* out_pairs, int32_t cap);
 
 /* main.cpp:64-76 for the tiles of p->rank: per-pixel fp32 colour sums over spp samples, written to

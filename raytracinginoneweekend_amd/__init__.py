@@ -51,7 +51,8 @@ class rtk_params(C.Structure):
 class rtk_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("sphere_tests", C.c_uint64), ("exact_tests", C.c_uint64),
                 ("lane_slots", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("frames", C.c_uint32),
-                ("frames_timed", C.c_uint32)]
+                ("frames_timed", C.c_uint32), ("max_wave_passes", C.c_uint64), ("waves", C.c_uint64),
+                ("drain_frac", C.c_float), ("reserved_", C.c_float)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

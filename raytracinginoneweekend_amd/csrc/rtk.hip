@@ -180,8 +180,8 @@ constexpr size_t kScratchBytes = kScratchAccumOff + static_cast<size_t>(kNoAlloc
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 // The run table of (spp, W, H, run_len), written by one thread into the static array (no host table, no copy).
-__global__ void runs_kernel(int spp, int width, int height, int run_len, uint2* out, int cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) fill_runs(spp, width, height, run_len, out, cap);
+__global__ void runs_kernel(int spp, long long n_pixels, int run_len, uint2* out, int cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fill_runs(spp, n_pixels, run_len, out, cap);
 }
 
 // =================================================================================================
@@ -237,9 +237,10 @@ struct rtk_context {
     bool have_scene = false;
     DevBuf filt, wdesc, exact, mat0, mat1;
     int class_words = 0;     // words of 32 spheres with 8-byte class records (rtk_scene_layout)
+    uint64_t last_waves = 0; // wavefronts of the last render launch
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
     std::vector<uint2> runs_host;
-    int runs_key[4] = {-1, -1, -1, -1};
+    int64_t runs_key[4] = {-1, -1, -1, -1};      // spp, local tiles, -, run_len of the resident table
     DevBuf accum;        // fixed-point accumulators
     size_t accum_zeroed = 0;   // number of accumulators known to be zero
     DevBuf control;      // queue counter (256 B) + stats
@@ -298,7 +299,7 @@ static int upload_grid(rtk_context* c) {
 // times of the context's frames.  Synchronises the context's stream.
 static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_counters) {
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[4];
+    unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     stats->rays = h[0];
@@ -307,6 +308,13 @@ static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_c
     stats->sphere_tests = use_grid(c) ? h[2] : h[0] * static_cast<uint64_t>(c->scene.n);
     stats->exact_tests = h[2];
     stats->lane_slots = h[3] * kWave;
+    stats->max_wave_passes = h[4];
+    stats->waves = c->last_waves;
+    {
+        const unsigned long long t0 = ~h[5], t_first = ~h[6], t_last = h[7];
+        stats->drain_frac = (h[5] != 0 && t_last > t0 && t_first >= t0) ? static_cast<float>(static_cast<double>(t_last - t_first) / static_cast<double>(t_last - t0)) : 0.0f;
+        stats->reserved_ = 0.0f;
+    }
     stats->frames = static_cast<uint32_t>(c->n_frames);
     stats->kernel_ms = 0.0f;
     stats->total_ms = 0.0f;
@@ -487,8 +495,8 @@ int64_t rtk_local_tile_count(int32_t W, int32_t H, int32_t tile_w, int32_t tile_
 }
 
 int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len, uint32_t* out_pairs, int32_t cap) {
-    if (spp <= 0 || width <= 0 || height <= 0 || run_len < 0) return fail(RTK_ERR_BAD_ARG, "rtk_run_schedule: spp %d, image %d x %d, run_len %d", spp, width, height, run_len);
-    const std::vector<uint2> runs = run_schedule(spp, width, height, run_len);
+    if (spp <= 0 || width <= 0 || height <= 0 || run_len < -4096) return fail(RTK_ERR_BAD_ARG, "rtk_run_schedule: spp %d, image %d x %d, run_len %d", spp, width, height, run_len);
+    const std::vector<uint2> runs = run_schedule(spp, static_cast<long long>(width) * height, run_len);
     const int n = static_cast<int>(runs.size());
     if (out_pairs) {
         if (cap < n) return fail(RTK_ERR_BAD_ARG, "rtk_run_schedule: %d runs do not fit in %d pairs", n, cap);
@@ -514,19 +522,20 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
 
     const int tiles_x = (p->width + tw - 1) / tw;
     const int64_t nlt = rtk_local_tile_count(p->width, p->height, tw, th, p->rank, world);
-    if (p->run_len < 0) return fail(RTK_ERR_BAD_ARG, "run_len must be >= 0, got %d", p->run_len);
+    if (p->run_len < -4096) return fail(RTK_ERR_BAD_ARG, "run_len must be >= -4096, got %d", p->run_len);
     int n_runs = 0;
+    const long long n_local_px = static_cast<long long>(nlt) * kTilePixels;      // the partition is sized for this rank's share
     if (static_ws) {
-        n_runs = fill_runs(p->spp, p->width, p->height, p->run_len, nullptr, 0);
+        n_runs = fill_runs(p->spp, n_local_px, p->run_len, nullptr, 0);
         if (n_runs > kNoAllocMaxRuns) return fail(RTK_ERR_TOO_LARGE, "rtk_render_tiles_device_noalloc: %d sample runs exceed the static table of %d (use fewer spp per call or a larger run_len)", n_runs, kNoAllocMaxRuns);
     } else {
-        if (c->runs_key[0] != p->spp || c->runs_key[1] != p->width || c->runs_key[2] != p->height || c->runs_key[3] != p->run_len) {
+        if (c->runs_key[0] != p->spp || c->runs_key[1] != nlt || c->runs_key[3] != p->run_len) {
             // a new sample partition: upload its table (the stream may still be reading the old one)
             HIP_TRY(hipStreamSynchronize(c->stream));
-            c->runs_host = run_schedule(p->spp, p->width, p->height, p->run_len);
+            c->runs_host = run_schedule(p->spp, n_local_px, p->run_len);
             HIP_TRY(c->runs.reserve(c->runs_host.size() * sizeof(uint2)));
             HIP_TRY(hipMemcpy(c->runs.p, c->runs_host.data(), c->runs_host.size() * sizeof(uint2), hipMemcpyHostToDevice));
-            c->runs_key[0] = p->spp; c->runs_key[1] = p->width; c->runs_key[2] = p->height; c->runs_key[3] = p->run_len;
+            c->runs_key[0] = p->spp; c->runs_key[1] = nlt; c->runs_key[2] = 0; c->runs_key[3] = p->run_len;
         }
         n_runs = static_cast<int>(c->runs_host.size());
     }
@@ -549,7 +558,7 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         HIP_TRY(hipMemsetAsync(accum, 0, n_acc * sizeof(unsigned long long), c->stream));
         HIP_TRY(hipMemsetAsync(control, 0, 512, c->stream));
-        hipLaunchKernelGGL(runs_kernel, dim3(1), dim3(64), 0, c->stream, p->spp, p->width, p->height, p->run_len, rt, kNoAllocMaxRuns);
+        hipLaunchKernelGGL(runs_kernel, dim3(1), dim3(64), 0, c->stream, p->spp, n_local_px, p->run_len, rt, kNoAllocMaxRuns);
         HIP_TRY(hipGetLastError());
         c->n_frames = 0;             // the counters are per call here
     } else {
@@ -598,6 +607,7 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
     const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
+    c->last_waves = static_cast<uint64_t>(grid) * kWavesPerBlock;
     const int slot = c->n_frames % rtk_context::kEventPairs;
     HIP_TRY(hipEventRecord(c->kev[2 * slot], c->stream));
     if (accel)

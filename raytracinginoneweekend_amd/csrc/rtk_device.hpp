@@ -142,6 +142,11 @@ struct Ray {
     V3 o, d;
 };
 
+// Constant-rate device clock (100 MHz), for the kernel's drain statistics only.
+#ifndef RTK_HOST_EMULATION
+__device__ __forceinline__ unsigned long long rtk_wall_clock() { return wall_clock64(); }
+#endif
+
 // Wave-level helpers (wave64).
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }

@@ -23,7 +23,7 @@ struct RenderArgs {
     uint32_t total_packets;
     unsigned long long* accum;   // [n_local_tiles][64][3] signed 32.32 fixed point
     uint32_t* queue;             // packet counter
-    unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector
+    unsigned long long* stats;   // [0] rays [1] samples [2] exact tests [3] wave passes through the intersector [4] most passes of one wave [5] ~earliest start [6] ~earliest end [7] latest end (100 MHz ticks)
     GridDev grid;                // only read by the GRID instantiation (rtk_context_set_accel)
 #ifdef RTK_HOST_EMULATION
     uint8_t* dbg_seg = nullptr;  // emulation only: [pixel][spp] segments traced per sample (work-distribution studies)
@@ -33,23 +33,22 @@ struct RenderArgs {
 // Persistent wavefronts.  A packet = one 64-pixel tile x one run of consecutive samples; a wavefront
 // draws packets from a global counter and hands the packet's 64 (pixel, run) units to whichever of
 // its lanes is free, so lanes whose path ended (sky, absorbed, depth exhausted) start the next sample
-// at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  A lane sums its
-// run in fp32 and adds the run total once, as 32.32 fixed point, to the pixel's accumulator: integer
-// adds commute, so the image is bit-identical for any scheduling, tile size and GPU count.
+// at once instead of idling behind the long-tail paths (SURVEY.md §7 hard part 3).  Every sample's
+// colour becomes 32.32 fixed point the moment its path ends; a lane sums its run in integers and adds
+// the run total to the pixel's accumulator: integer adds commute and associate, so the image is
+// bit-identical for any scheduling, run partition, tile size and GPU count.
 constexpr int kDequeue = 2;      // packets a wavefront draws from the queue per atomic
 
-// fp32 run sum -> signed 32.32 fixed point (two's complement in a u64), entirely in fp32/integer instructions (f64
-// conversions run at a fraction of the fp32 rate and this executes in nearly every pass).  Integer part = floor,
-// fraction rounded to nearest-even 2^-32; NaN contributes 0, magnitudes are clamped to +-2^30.  Any deterministic map
-// would do — integer accumulation is what makes the image independent of scheduling — this one is exact for every
-// non-negative sum (f - floor(f) and its scaling by 2^32 are exact in fp32).
+// fp32 sample colour -> signed 32.32 fixed point (two's complement in a u64), entirely in fp32/integer instructions (f64
+// conversions run at a fraction of the fp32 rate and this executes in every pass).  Integer part = floor, fraction
+// truncated to 2^-32 (exact whenever the fraction's ulp is at least 2^-32); NaN contributes 0, magnitudes are clamped
+// to +-2^30.  Any deterministic map would do — integer accumulation is what makes the image independent of scheduling.
 __device__ __forceinline__ unsigned long long to_fixed_32_32(float f) {
     const float lim = 0x1p30f;
     const float c = (f == f) ? fminf(fmaxf(f, -lim), lim) : 0.0f;
-    float hi = floorf(c);
-    float frac = c - hi;                       // [0, 1]; can round up to 1 only for tiny negative c
-    if (frac >= 1.0f) { hi += 1.0f; frac = 0.0f; }
-    const uint32_t lo = static_cast<uint32_t>(rintf(frac * 4294967296.0f));      // < 2^32
+    const float hi = floorf(c);
+    const float frac = fminf((c - hi) * 4294967296.0f, 4294967040.0f);      // [0, 2^32): c - hi can round up to 1 only for tiny negative c
+    const uint32_t lo = static_cast<uint32_t>(frac);
     const uint32_t top = static_cast<uint32_t>(static_cast<int32_t>(hi));
     return (static_cast<unsigned long long>(top) << 32) | lo;
 }
@@ -61,10 +60,12 @@ template <bool LDS, bool GRID = false>
 __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect, const CameraDev* cam) {
     const int lane = isect.lane;
     const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
+    const unsigned long long t_begin = rtk_wall_clock();
 
     // lane state
     Ray ray = {};
-    V3 thr = {0, 0, 0}, acc = {0, 0, 0};
+    V3 thr = {0, 0, 0};
+    unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;      // this unit's colour sums, 32.32 fixed point
     bool alive = false, has_unit = false;
     int depth_left = 0, unit_left = 0;
     uint32_t pixel = 0, slot = 0, sample = 0, bounce = 0;
@@ -88,11 +89,10 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 start = true;
             } else {
                 if (has_unit) {
-                    const unsigned long long qr = to_fixed_32_32(acc.x), qg = to_fixed_32_32(acc.y), qb = to_fixed_32_32(acc.z);
                     unsigned long long* dst = A.accum + static_cast<size_t>(slot) * 3;
-                    atomicAdd(dst + 0, qr);
-                    atomicAdd(dst + 1, qg);
-                    atomicAdd(dst + 2, qb);
+                    atomicAdd(dst + 0, acc_r);
+                    atomicAdd(dst + 1, acc_g);
+                    atomicAdd(dst + 2, acc_b);
                     has_unit = false;
                 }
                 need = true;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                     slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
                     sample = pk_first + A.sample_offset;
                     unit_left = static_cast<int>(pk_len) - 1;
-                    acc = {0, 0, 0};
+                    acc_r = acc_g = acc_b = 0;
                     has_unit = true;
                     start = true;
                     need = false;
@@ -192,7 +192,10 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + (sample - A.sample_offset)];
 #endif
             if (idx < 0) {
-                acc = acc + thr * sky_unit(ud);            // main.cpp:98-100
+                const V3 c = thr * sky_unit(ud);           // main.cpp:98-100: the only non-zero outcome of a path
+                acc_r += to_fixed_32_32(c.x);
+                acc_g += to_fixed_32_32(c.y);
+                acc_b += to_fixed_32_32(c.z);
                 alive = false;
             } else {
                 ++bounce;
@@ -211,7 +214,15 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
     atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
     atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
-    if (lane == 0) atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
+    if (lane == 0) {
+        atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
+        atomicMax(A.stats + 4, static_cast<unsigned long long>(wave_passes));
+        // kernel start (earliest), first and last wave to run out of work: ~t so that the zeroed counter is the identity of max
+        atomicMax(A.stats + 5, ~t_begin);
+        const unsigned long long t_end = rtk_wall_clock();
+        atomicMax(A.stats + 6, ~t_end);
+        atomicMax(A.stats + 7, t_end);
+    }
 }
 
 

@@ -337,17 +337,19 @@ inline void build_grid(const rtk_scene* s, const PreparedScene& ps, GridHost& g)
     g.usable = true;
 }
 
-// The partition of a pixel's `spp` samples into runs (a lane sums one run in fp32, then adds it to the pixel's
-// integer accumulator).  It depends on spp and the image size ONLY, never on the GPU count or the scheduling, so
-// images stay bit-identical across ranks.  run_len > 0: equal runs of that length.  run_len == 0 (default):
-// decreasing runs, L = ceil(remaining / k): units are large while there is plenty of work and shrink towards
-// the end of the frame, so that no lane is still inside a long unit when the packet queue runs dry (the tail
-// sets the kernel's end; hot pixels — glass interiors — cost up to 7x the mean per sample).  k grows as the
-// frame shrinks (fewer pixels per lane -> the tail matters more): k = clamp(66.7e6 / (W*H), 8, 64), sized for
-// the frame being split over up to 8 GPUs (tools/sim_schedule.py).
+// The partition of a pixel's `spp` samples into runs (a lane traces one run of one pixel, then adds its integer colour
+// sums to the pixel's accumulator).  Every SAMPLE is converted to fixed point before it is summed, so the image does not
+// depend on the partition at all: it is chosen per rank for load balance alone.  run_len > 0: equal runs of that
+// length.  run_len == 0 (default): decreasing runs, L = ceil(remaining / k): units are large while there is plenty of
+// work and single samples at the end of the frame, so that no lane is still inside a long unit when the packet queue
+// runs dry (the tail sets the kernel's end; hot pixels — glass interiors — cost up to 7x the mean per sample, and a
+// wave that its SIMD's arbiter favours least runs at a third of the mean rate).  k grows as the rank's share shrinks
+// (fewer pixels per lane -> the tail matters more): k = clamp(3e7 / pixels of this rank, 32, 256) — measured on the
+// 1200x800x500 frame (tools/sched_sweep.py): k = 32 at 1 GPU (106 runs, 108.3 ms), k = 250 for an eighth of it
+// (15.3 ms instead of 17.3 with k = 64).  run_len < 0: decreasing runs with k = -run_len (schedule studies).
 // fill_runs: the table itself, usable from host and device code (the entry point that allocates nothing builds it with
 // a one-thread kernel straight into its static device array).  Returns the number of runs; writes at most `cap`.
-__host__ __device__ inline int fill_runs(int spp, int width, int height, int run_len, uint2* out, int cap) {
+__host__ __device__ inline int fill_runs(int spp, long long n_pixels, int run_len, uint2* out, int cap) {
     int n = 0;
     if (spp <= 0) return 0;
     if (run_len > 0) {
@@ -355,10 +357,10 @@ __host__ __device__ inline int fill_runs(int spp, int width, int height, int run
             if (n < cap) out[n] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(run_len < spp - s ? run_len : spp - s));
         return n;
     }
-    const double px = static_cast<double>(width) * static_cast<double>(height);
-    double kd = ceil(66.7e6 / (px > 1.0 ? px : 1.0));
-    kd = kd < 8.0 ? 8.0 : (kd > 64.0 ? 64.0 : kd);
-    const int k = static_cast<int>(kd);
+    const double px = static_cast<double>(n_pixels);
+    double kd = ceil(3.0e7 / (px > 1.0 ? px : 1.0));
+    kd = kd < 32.0 ? 32.0 : (kd > 256.0 ? 256.0 : kd);
+    const int k = run_len < 0 ? -run_len : static_cast<int>(kd);      // run_len < 0: decreasing runs with k = -run_len (schedule studies)
     for (int s = 0; s < spp; ++n) {
         const int rem = spp - s;
         const int len = (rem + k - 1) / k;          // >= 1
@@ -368,9 +370,9 @@ __host__ __device__ inline int fill_runs(int spp, int width, int height, int run
     return n;
 }
 
-inline std::vector<uint2> run_schedule(int spp, int width, int height, int run_len) {
-    std::vector<uint2> runs(static_cast<size_t>(fill_runs(spp, width, height, run_len, nullptr, 0)));
-    fill_runs(spp, width, height, run_len, runs.data(), static_cast<int>(runs.size()));
+inline std::vector<uint2> run_schedule(int spp, long long n_pixels, int run_len) {
+    std::vector<uint2> runs(static_cast<size_t>(fill_runs(spp, n_pixels, run_len, nullptr, 0)));
+    fill_runs(spp, n_pixels, run_len, runs.data(), static_cast<int>(runs.size()));
     return runs;
 }
 

@@ -217,11 +217,11 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
     const int tiles_x = (p->width + tw - 1) / tw;
     const int64_t tiles = static_cast<int64_t>(tiles_x) * ((p->height + th - 1) / th);
     const int64_t nlt = (tiles - p->rank + world - 1) / world;
-    const std::vector<uint2> runs = run_schedule(p->spp, p->width, p->height, p->run_len);
+    const std::vector<uint2> runs = run_schedule(p->spp, static_cast<long long>(nlt) * kTilePixels, p->run_len);
     const int n_runs = static_cast<int>(runs.size());
     std::vector<unsigned long long> accum(static_cast<size_t>(nlt) * kTilePixels * 3, 0ull);
     uint32_t queue = 0;
-    unsigned long long stats[4] = {0, 0, 0, 0};
+    unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RenderArgs A;
     A.scene = e.dev;
     std::memcpy(&A.cam, cam22, 88);

@@ -40,6 +40,12 @@ inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 #endif
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long rtk_wall_clock() { return 0ull; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+    unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 namespace rtk_shim {
 extern thread_local int ulp_noise;      // 0: libm values; k > 0: pseudo-random perturbation within +-k ulp

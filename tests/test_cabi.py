@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(rt.rtk_camera) == 88
     assert C.sizeof(rt.rtk_scene) == 8 + 11 * 8
     assert C.sizeof(rt.rtk_params) == 56
-    assert C.sizeof(rt.rtk_stats) == 56
+    assert C.sizeof(rt.rtk_stats) == 80
 
 
 def test_local_tile_count():
@@ -60,7 +60,7 @@ def test_no_device_fails_loudly():
 
 
 def test_run_schedule_partitions_the_samples():
-    """rtk_run_schedule (host only): runs tile [0, spp) exactly, never depend on rank/world, shrink towards the end."""
+    """rtk_run_schedule (host only): runs tile [0, spp) exactly and shrink towards the end; finer for fewer pixels."""
     import numpy as np
     for spp, W, H, rl in [(500, 1200, 800, 0), (1000, 3840, 2160, 0), (10, 400, 225, 0), (1, 16, 16, 0), (500, 120, 80, 0), (500, 1200, 800, 8), (7, 64, 48, 3), (40, 64, 48, 40), (5, 64, 48, 9)]:
         r = rt.run_schedule(spp, W, H, rl)
@@ -71,10 +71,15 @@ def test_run_schedule_partitions_the_samples():
             assert r[-1, 1] == 1 or spp < 8                            # the frame ends on single-sample units
         else:
             assert (r[:-1, 1] == min(rl, spp)).all()
-    # C2: k = 64 -> first run 8 samples, 172 runs, the last 64 samples one by one; C3: k = 9 -> first run 112 samples
+    # C2 on one GPU: k = 32 -> first run 16 samples, 106 runs, the last 31 samples one by one; an eighth of it (one of 8
+    # ranks): k = 250 -> single samples almost from the start; C3: k = 32 -> first run 32 samples
     c2 = rt.run_schedule(500, 1200, 800)
-    assert c2[0, 1] == 8 and len(c2) == 172 and (c2[:, 1] == 1).sum() == 64
-    assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 112
+    assert c2[0, 1] == 16 and len(c2) == 106 and (c2[:, 1] == 1).sum() == 31
+    c2_8 = rt.run_schedule(500, 1200, 100)
+    assert c2_8[0, 1] == 2 and (c2_8[:, 1] == 1).sum() == 250
+    assert rt.run_schedule(1000, 3840, 2160)[0, 1] == 32
+    # run_len < 0: decreasing runs with k = -run_len
+    assert rt.run_schedule(500, 1200, 800, -64)[0, 1] == 8 and len(rt.run_schedule(500, 1200, 800, -64)) == 172
     assert rt.lib().rtk_run_schedule(0, 10, 10, 0, None, 0) == -1
 
 
