@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
   roofline     : the render kernel against the FP32 vector peak, algorithmic flops = 17 per ray-sphere
                  test x 484 spheres per ray, kernel time from HIP events on the kernel's stream
   cpu_baseline : the reference compiled unmodified (oracle/_ref/rtiow_ref, kind "reference") or, if that
-                 binary is absent, the oracle restatement (kind "port"), one thread, on a bounded sample (~10 s).
+                 binary is absent, the oracle restatement (kind "port"), one thread, on BASELINE.json configs[0]
+                 in full (400x225, 10 spp, depth 50: ~20 s; its rays and output hash are pinned).
 """
 from __future__ import annotations
 
@@ -45,39 +46,46 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
 KERNEL_TAG = "r02-c (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius, candidate mask words kept in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
 
 
+# BASELINE.json configs[0] — the reference's own CPU-runnable case: `400 225 10 50`.  The reference is deterministic
+# (default-seeded mt19937 statics), so this run always traces the same rays and writes the same file: both are pinned
+# (tests/test_oracle_golden.py checks the oracle reproduces them).
+C1_ARGV = ["400", "225", "10", "50"]
+C1_RAYS = 2604684
+C1_PPM_SHA256 = "f87897196e761b05544c5dcd940b34128661b94e2ff10402ac4859aae7e31c34"
+
+
 def cpu_baseline():
-    """Single-thread CPU time of the same scene/camera/depth on a bounded sample of the workload."""
+    """Single-thread CPU time of the reference on BASELINE.json configs[0] (same scene, camera and depth as the GPU
+    workload; 0.9 M samples, ~20 s): the compiled reference itself, else the oracle restatement."""
+    import hashlib
     from oracle import pyoracle as po   # the only place bench.py touches oracle/: the baseline leg
     ref_bin = po.REF_BINARY_PATH
     cores = 1
+    W1, H1, spp1 = int(C1_ARGV[0]), int(C1_ARGV[1]), int(C1_ARGV[2])
     try:
         if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
-            # the reference executable renders whole images only: same scene, camera aspect (3:2) and depth,
-            # reduced resolution and spp; its own ProfileLogScope times the "Image Generation" scope (main.cpp:63)
-            argv = ["300", "200", "12", str(DEPTH)]        # ~10 s of single-thread CPU work
+            # its own ProfileLogScope times the "Image Generation" scope (main.cpp:63)
             with tempfile.TemporaryDirectory() as td:
-                r = subprocess.run([ref_bin, *argv], cwd=td, capture_output=True, text=True, timeout=600)
+                r = subprocess.run([ref_bin, *C1_ARGV], cwd=td, capture_output=True, text=True, timeout=900)
+                sha = hashlib.sha256(open(os.path.join(td, "image_binary.ppm"), "rb").read()).hexdigest()
             m = re.search(r"Image Generation took ([0-9.eE+-]+) seconds", r.stderr)
             secs = float(m.group(1))
-            # rays of that exact run: the oracle renders the bit-identical image (golden hashes), so its count is the reference's
-            o = po.Oracle()
-            o.random_scene()
-            _, _, seg = o.render_rows(po.stock_camera(1.5), 300, 200, 12, DEPTH, want_u8=False)
-            return {"value": seg / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
-                    "sample": "reference executable (g++ -O2 -ffp-contract=off, unmodified sources), stock scene, 300x200, 12 spp, depth 50: "
-                              "%d rays in %.2f s (its own 'Image Generation' scope)" % (seg, secs),
-                    "samples_per_s": 300 * 200 * 12 / secs}
+            if sha != C1_PPM_SHA256:
+                raise RuntimeError("the reference binary wrote an image with an unexpected hash " + sha)
+            return {"value": C1_RAYS / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                    "sample": "BASELINE.json configs[0] in full: reference executable (g++ -O2 -ffp-contract=off, unmodified sources), final scene, "
+                              "400x225, 10 spp, depth 50: %d rays in %.2f s (its own 'Image Generation' scope; output PPM hash = golden)" % (C1_RAYS, secs),
+                    "samples_per_s": W1 * H1 * spp1 / secs}
     except Exception as e:   # fall through to the port
         print("cpu_baseline: reference binary failed (%s); timing the oracle port instead" % e, file=sys.stderr)
     o = po.Oracle()
     o.random_scene()
-    rows = (400, 404)
     t0 = time.perf_counter()
-    _, _, seg = o.render_rows(po.stock_camera(W / H), W, H, SPP, DEPTH, rows[0], rows[1], want_u8=False)
+    _, u8, seg = o.render_rows(po.stock_camera(po.cli_dims(C1_ARGV)[4]), W1, H1, spp1, int(C1_ARGV[3]))
     secs = time.perf_counter() - t0
     return {"value": seg / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "oracle/cpu_ref.cpp (-O2 -ffp-contract=off), rows %d-%d of the 1200x800 500-spp frame: %d rays in %.2f s" % (rows[0], rows[1] - 1, seg, secs),
-            "samples_per_s": (rows[1] - rows[0]) * W * SPP / secs}
+            "sample": "BASELINE.json configs[0] in full: oracle/cpu_ref.cpp (-O2 -ffp-contract=off), 400x225, 10 spp, depth 50: %d rays in %.2f s" % (seg, secs),
+            "samples_per_s": W1 * H1 * spp1 / secs}
 
 
 def main():

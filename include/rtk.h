@@ -248,6 +248,12 @@ int rtk_primary_rays(rtk_context* ctx, const rtk_camera* cam, const rtk_params* 
  * p->seed; HOST arrays; for known-answer tests. */
 int rtk_philox_batch(rtk_context* ctx, uint64_t seed, const uint32_t* ctr4, size_t n, uint32_t* out4);
 
+/* The direct sampling maps the kernels use in place of the reference's rejection samplers (same distributions):
+ * kind 0 = uniform in the unit ball (Vector3.cpp:3-9), 1 = uniform on the unit sphere (Vector3.cpp:49-51),
+ * 2 = uniform in the unit disk (Vector3.cpp:53-59; z = 0).  u4 = n x 4 uniforms in [0,1) as the kernels hand them
+ * over (ball: u0 u1 u2; sphere: u0 u1; disk: u2 u3 — the slots the render kernel uses); out3 = n x 3.  Parity entry point. */
+int rtk_sample_batch(rtk_context* ctx, int32_t kind, const float* u4, size_t n, float* out3);
+
 /* Block until everything queued on the context's stream has finished. */
 int rtk_synchronize(rtk_context* ctx);
 

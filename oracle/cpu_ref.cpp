@@ -491,6 +491,22 @@ void oracle_sample(void* h, int kind, uint64_t n, float* out3) {
     }
 }
 
+// main.cpp:69-71 for given pixel positions and GIVEN random numbers: u = (x + xi0) / (W - 1), v = (y + xi1) / (H - 1)
+// with y = H - 1 - row, then Camera::get_ray(u, v) (Camera.hpp:25-29) with `disk` standing in for
+// random_in_unit_disk().  xy = (x, row) pairs, xi = pixel jitter pairs, disk = lens samples; out6 = origin, direction.
+void oracle_primary_batch(const float* cam22, int W, int H, const int32_t* xy, const float* xi, const float* disk, uint64_t n, float* out6) {
+    Cam cam;
+    std::memcpy(&cam, cam22, sizeof(float) * 22);
+    for (uint64_t i = 0; i < n; ++i) {
+        const int x = xy[2 * i], y = H - 1 - xy[2 * i + 1];
+        const float u = (x + xi[2 * i]) / (W - 1);
+        const float v = (y + xi[2 * i + 1]) / (H - 1);
+        const Ray r = get_ray(cam, u, v, V3{disk[2 * i], disk[2 * i + 1], 0.0f});
+        float* o = out6 + 6 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+    }
+}
+
 // main.cpp:62-78: the pixel/sample loops over rows [row_begin, row_end) counted from the TOP of the
 // image (row 0 is y = H-1).  Writes the fp32 per-pixel colour sums (row-major from the top, RGB) and,
 // if `out_u8` is non-null, the write_color_binary bytes.  The RNG streams continue from wherever the

@@ -56,6 +56,7 @@ def _load() -> C.CDLL:
     lib.oracle_depth_outs.argtypes = [C.c_void_p]
     lib.oracle_depth_outs.restype = C.c_uint64
     lib.oracle_quantise.argtypes = [_f32p, C.c_uint64, C.c_int, _u8p]
+    lib.oracle_primary_batch.argtypes = [_f32p, C.c_int, C.c_int, _i32p, _f32p, _f32p, C.c_uint64, _f32p]
     return lib
 
 
@@ -176,6 +177,15 @@ class Oracle:
 
     def depth_outs(self) -> int:
         return int(self._l.oracle_depth_outs(self._h))
+
+
+def primary_rays(cam22, W, H, xy, xi, disk) -> np.ndarray:
+    """main.cpp:69-71 + Camera::get_ray for pixel (x, row-from-top) pairs with given jitter and lens samples -> [n, 6]."""
+    xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+    out = np.zeros((xy.shape[0], 6), np.float32)
+    lib().oracle_primary_batch(np.ascontiguousarray(cam22, np.float32), W, H, xy, np.ascontiguousarray(xi, np.float32).reshape(-1, 2),
+                               np.ascontiguousarray(disk, np.float32).reshape(-1, 2), xy.shape[0], out)
+    return out
 
 
 def quantise(sums: np.ndarray, spp: int) -> np.ndarray:

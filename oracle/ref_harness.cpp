@@ -70,6 +70,39 @@ void ref_list_hit(int n, const float* cx, const float* cy, const float* cz, cons
     }
 }
 
+// The same with NESTED lists (HittableList.hpp:20-27: a HittableList is itself a Hittable): every `nest` consecutive
+// spheres sit in an inner reference HittableList; sphere k (k % 7 == 3) additionally gets a list of its own two levels
+// down.  `tags` must list every sphere in the order the reference visits them (= the order a flatten must produce).
+void ref_nested_list_hit(int n, const float* cx, const float* cy, const float* cz, const float* radius, int nest, const float* rays,
+                         uint64_t nrays, float t_min, float t_max, uint8_t* out_hit, int32_t* out_index, float* out_t) {
+    HittableList world{};
+    std::shared_ptr<HittableList> inner;
+    for (int i = 0; i < n; ++i) {
+        Material m{};
+        m.color = Color{static_cast<float>(i), 0.0f, 0.0f};
+        std::shared_ptr<Hittable> s = std::make_shared<Sphere3>(Point3{cx[i], cy[i], cz[i]}, radius[i], m);
+        if (i % 7 == 3) s = std::make_shared<HittableList>(std::make_shared<HittableList>(s));     // a list in a list around one sphere
+        if (nest > 0) {
+            if (i % nest == 0) {
+                inner = std::make_shared<HittableList>();
+                world.add(inner);
+            }
+            inner->add(s);
+        } else {
+            world.add(s);
+        }
+    }
+    for (uint64_t i = 0; i < nrays; ++i) {
+        const float* q = rays + 6 * i;
+        const Ray3 r{Point3{q[0], q[1], q[2]}, Vector3{q[3], q[4], q[5]}};
+        hit_record rec{};
+        const bool hit = world.hit(r, t_min, t_max, rec);
+        out_hit[i] = hit ? 1 : 0;
+        out_index[i] = hit ? static_cast<int32_t>(rec.material.color.x()) : -1;
+        out_t[i] = hit ? rec.t : 0.0f;
+    }
+}
+
 // Sphere3::hit (Sphere3.hpp:31-59), one sphere per ray.  out9 = p, normal, t, front_face, hit.
 void ref_sphere_hit(const float* centers, const float* radius, const float* rays, uint64_t n, float t_min, float t_max,
                     float* out9) {

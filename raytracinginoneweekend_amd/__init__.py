@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = (
     "rtk_quantise_device", "rtk_intersect_batch", "rtk_intersect_batch_device", "rtk_scatter_batch",
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
     "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8", "rtk_context_set_accel", "rtk_accel_in_use",
-    "rtk_render_tiles_device_noalloc", "rtk_scene_layout",
+    "rtk_render_tiles_device_noalloc", "rtk_scene_layout", "rtk_sample_batch",
 )
 ACCEL_LIST, ACCEL_GRID = 0, 1
 
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         l.rtk_scatter_batch.argtypes = [vp, vp, vp, vp, vp, sz, vp]
         l.rtk_primary_rays.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, sz, vp]
         l.rtk_philox_batch.argtypes = [vp, u64, vp, sz, vp]
+        l.rtk_sample_batch.argtypes = [vp, i32, vp, sz, vp]
         l.rtk_synchronize.argtypes = [vp]
         l.rtk_reset_stats.argtypes = [vp]
         l.rtk_get_stats.argtypes = [vp, C.POINTER(rtk_stats)]
@@ -124,6 +125,7 @@ def host_lib() -> C.CDLL:
         h.rtiow_host_random_scene.argtypes = [C.c_int] + [fp] * 10 + [ip]
         h.rtiow_host_scaled_scene.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_int] + [fp] * 10 + [ip]
         h.rtiow_host_camera.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+        h.rtiow_host_flatten_nested.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int] + [fp] * 10 + [ip]
         h.rtiow_host_list_hit.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, fp, C.c_uint64, C.c_float, C.c_float, up, ip, fp]
         h.rtiow_host_write_color_binary.argtypes = [fp, C.c_uint64, C.c_int, up]
         h.rtiow_host_write_ppm.argtypes = [C.c_int, C.c_int, fp, C.c_int, up, C.c_int64]
@@ -152,6 +154,18 @@ def scaled_scene(k: int = 11, diffuse_below: float = 0.8, metal_below: float = 0
     if n < 0:
         raise RtkError("scene capacity too small")
     return {f: a[:n].copy() for f, a in zip(SCENE_FIELDS, arrs)}
+
+
+def flatten_nested(cx, cy, cz, radius, nest: int) -> dict:
+    """A user scene built from nested HittableLists with the host classes (every `nest` spheres in an inner list, some
+    wrapped two levels deeper) and flattened by rtiow::flatten: the arrays rtk_set_scene takes, in the reference's visiting order."""
+    n = len(cx)
+    arrs = _scene_arrays(n + 8)
+    f = lambda a: np.ascontiguousarray(a, np.float32)   # noqa: E731
+    got = host_lib().rtiow_host_flatten_nested(n, f(cx), f(cy), f(cz), f(radius), nest, n + 8, *arrs)
+    if got < 0:
+        raise RtkError("scene capacity too small")
+    return {k: a[:got].copy() for k, a in zip(SCENE_FIELDS, arrs)}
 
 
 def stock_scene() -> dict:
@@ -333,6 +347,13 @@ class Context:
         cam = _cam_struct(cam22)
         _check(self._l.rtk_primary_rays(self._h, C.byref(cam), C.byref(p), xys.ctypes.data, xys.shape[0], out.ctypes.data),
                "rtk_primary_rays")
+        return out
+
+    def sample(self, kind: int, u4):
+        """The kernels' direct sampling maps: kind 0 ball, 1 unit sphere, 2 disk; u4 [n, 4] uniforms -> [n, 3]."""
+        u4 = np.ascontiguousarray(u4, np.float32).reshape(-1, 4)
+        out = np.zeros((u4.shape[0], 3), np.float32)
+        _check(self._l.rtk_sample_batch(self._h, kind, u4.ctypes.data, u4.shape[0], out.ctypes.data), "rtk_sample_batch")
         return out
 
     def philox(self, seed: int, ctr4):

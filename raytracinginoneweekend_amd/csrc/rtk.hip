@@ -162,6 +162,17 @@ __global__ void primary_kernel(const CameraDev cam, int W, int H, uint32_t seed_
     o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
 }
 
+__global__ void sample_kernel(int kind, const float* u4, size_t n, float* out3) {
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const float* u = u4 + 4 * i;
+    V3 v = {0.0f, 0.0f, 0.0f};
+    if (kind == 0) v = sample_in_unit_sphere(u[0], u[1], u[2]);
+    else if (kind == 1) v = sample_unit_vector(u[0], u[1]);
+    else sample_disk(u[2], u[3], v.x, v.y);
+    out3[3 * i] = v.x; out3[3 * i + 1] = v.y; out3[3 * i + 2] = v.z;
+}
+
 __global__ void philox_kernel(uint32_t seed_lo, uint32_t seed_hi, const uint32_t* ctr4, size_t n, uint32_t* out4) {
     const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
     if (i >= n) return;
@@ -843,6 +854,22 @@ int rtk_primary_rays(rtk_context* c, const rtk_camera* cam, const rtk_params* p,
                        static_cast<uint32_t>(p->seed >> 32), static_cast<const int32_t*>(c->scratch_a.p), n, static_cast<float*>(c->scratch_e.p));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_rays, c->scratch_e.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+int rtk_sample_batch(rtk_context* c, int32_t kind, const float* u4, size_t n, float* out3) {
+    if (!c || !out3 || (!u4 && n)) return fail(RTK_ERR_BAD_ARG, "rtk_sample_batch: null argument");
+    if (kind < 0 || kind > 2) return fail(RTK_ERR_BAD_ARG, "rtk_sample_batch: kind %d (0 ball, 1 sphere, 2 disk)", kind);
+    if (n == 0) return RTK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch_a.reserve(n * 16));
+    HIP_TRY(c->scratch_e.reserve(n * 12));
+    HIP_TRY(hipMemcpyAsync(c->scratch_a.p, u4, n * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(sample_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, c->stream, kind, static_cast<const float*>(c->scratch_a.p), n,
+                       static_cast<float*>(c->scratch_e.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out3, c->scratch_e.p, n * 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTK_OK;
 }

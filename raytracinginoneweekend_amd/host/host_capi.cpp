@@ -126,6 +126,30 @@ void rtiow_host_list_hit(int n, const float* cx, const float* cy, const float* c
     }
 }
 
+// The nested world of oracle/ref_harness.cpp ref_nested_list_hit, built with THIS repository's host classes and
+// flattened (rtiow::flatten expands nested lists in place): the SoA arrays rtk_set_scene takes.  Material: Lambertian
+// whose red channel is the sphere's position in the build order (so a test can see the order flatten produced).
+int rtiow_host_flatten_nested(int n, const float* cx, const float* cy, const float* cz, const float* radius, int nest, int cap, float* ocx, float* ocy,
+                              float* ocz, float* oradius, float* mr, float* mg, float* mb, float* rough, float* metallic, float* ior, int32_t* type) {
+    HittableList world{};
+    std::shared_ptr<HittableList> inner;
+    for (int i = 0; i < n; ++i) {
+        Material m = make_lambertian(MaterialDesc{Color{static_cast<float>(i), 0.5f, 0.5f}});
+        std::shared_ptr<Hittable> s = std::make_shared<Sphere3>(Point3{cx[i], cy[i], cz[i]}, radius[i], m);
+        if (i % 7 == 3) s = std::make_shared<HittableList>(std::make_shared<HittableList>(s));
+        if (nest > 0) {
+            if (i % nest == 0) {
+                inner = std::make_shared<HittableList>();
+                world.add(inner);
+            }
+            inner->add(s);
+        } else {
+            world.add(s);
+        }
+    }
+    return copy_out(rtiow::flatten(world), cap, ocx, ocy, ocz, oradius, mr, mg, mb, rough, metallic, ior, type);
+}
+
 // write_color_binary over an array of RGB sums.
 void rtiow_host_write_color_binary(const float* sums, uint64_t npixels, int spp, uint8_t* out) {
     std::ostringstream os(std::ios_base::binary);

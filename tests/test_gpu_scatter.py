@@ -153,3 +153,50 @@ def test_primary_rays_vs_camera_model(gpu_ctx):
     assert np.allclose(got[:, 0:3], o, atol=1e-6) and np.allclose(got[:, 3:6], d, atol=2e-6)
     # u, v stay inside the viewport: every primary ray of the stock camera points roughly at the origin
     assert (got[:, 3] < 0).all()
+
+
+def test_sample_batch_is_what_scatter_uses_and_disk_matches_reference_distribution(gpu_ctx):
+    """rtk_sample_batch exposes the kernels' direct maps.  (1) The unit-sphere and ball maps are the draws seen through
+    Material::scatter above; (2) the DISK map (lens samples of Camera::get_ray) has the distribution of the reference's
+    random_in_unit_disk (Vector3.cpp:53-59; 4096 recorded samples in samplers.npz): moments, radial CDF, inside the disk."""
+    z = load_golden("samplers.npz")
+    n = 200000
+    u = np.random.default_rng(5).uniform(0, 1, (n, 4)).astype(np.float32)
+    disk = gpu_ctx.sample(2, u).astype(np.float64)
+    ref = z["in_disk"].astype(np.float64)
+    assert not disk[:, 2].any() and not ref[:, 2].any()
+    rad = np.linalg.norm(disk[:, :2], axis=1)
+    assert (rad < 1.0 + 1e-6).all()
+    se = 4.5 / np.sqrt(len(ref))
+    assert np.all(np.abs(disk.mean(0) - ref.mean(0)) < se) and np.all(np.abs((disk ** 2).mean(0) - (ref ** 2).mean(0)) < se)
+    assert abs((disk[:, 0] * disk[:, 1]).mean() - (ref[:, 0] * ref[:, 1]).mean()) < se
+    for r in (0.25, 0.5, 0.75, 0.9):                                     # uniform in area: P(|p| < r) = r^2
+        assert abs((rad < r).mean() - (np.linalg.norm(ref[:, :2], axis=1) < r).mean()) < se
+        assert abs((rad < r).mean() - r * r) < 4.5 * np.sqrt(r * r * (1 - r * r) / n) + 1e-4
+    for q in range(8):                                                   # uniform in angle
+        ang = np.arctan2(disk[:, 1], disk[:, 0])
+        assert abs(((ang >= -np.pi + q * np.pi / 4) & (ang < -np.pi + (q + 1) * np.pi / 4)).mean() - 0.125) < 4.5 * np.sqrt(0.125 * 0.875 / n)
+    # the sphere map is on the sphere, the ball map inside the ball
+    assert np.allclose(np.linalg.norm(gpu_ctx.sample(1, u), axis=1), 1.0, atol=2e-6)
+    assert (np.linalg.norm(gpu_ctx.sample(0, u), axis=1) <= 1.0 + 1e-6).all()
+
+
+def test_primary_rays_bit_exact_vs_oracle_get_ray(gpu_ctx):
+    """main.cpp:69-71 + Camera::get_ray (Camera.hpp:25-29): the GPU's primary rays against the ORACLE's get_ray fed the same
+    pixel jitter (the Philox uniforms) and the GPU's own lens sample (rtk_sample_batch) — origin and direction bit for bit."""
+    for W, H in ((200, 112), (1200, 800), (3840, 2160)):
+        seed = 4242 + W
+        cam = rt.stock_camera(float(np.float32(W) / np.float32(H)))
+        rng = np.random.default_rng(W)
+        n = 20000
+        xys = np.stack([rng.integers(0, W, n), rng.integers(0, H, n), rng.integers(0, 1000, n)], 1).astype(np.int32)
+        xys[:4] = [[0, 0, 0], [W - 1, 0, 1], [0, H - 1, 2], [W - 1, H - 1, 3]]             # the four corners
+        got = gpu_ctx.primary_rays(cam, W, H, xys, seed)
+        ctr = np.zeros((n, 4), np.uint32)
+        ctr[:, 0] = xys[:, 1].astype(np.uint32) * np.uint32(W) + xys[:, 0].astype(np.uint32); ctr[:, 1] = xys[:, 2]
+        r = philox4x32_10(ctr, (seed & 0xffffffff, seed >> 32))
+        u = np.stack([u01(r[:, i]) for i in range(4)], 1).astype(np.float32)
+        assert np.array_equal(gpu_ctx.philox(seed, ctr), r)
+        disk = gpu_ctx.sample(2, u)
+        want = po.primary_rays(cam, W, H, xys[:, :2], u[:, :2], disk[:, :2])
+        assert np.array_equal(bits(got), bits(want)), (W, H)

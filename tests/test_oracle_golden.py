@@ -33,6 +33,24 @@ def test_oracle_ppm_hash(argv):
     assert po.reference_main_ppm_sha256(argv.split()) == HASHES[argv]
 
 
+def test_bench_pins_config1_rays_and_hash():
+    """bench.py's cpu_baseline leg prices the reference's run of BASELINE.json configs[0] with a pinned ray count and
+    checks its PPM hash: both are what the hash-pinned oracle gives for that argv."""
+    import hashlib, importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_consts", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    src = open(spec.origin).read()
+    consts = {}
+    for name in ("C1_ARGV", "C1_RAYS", "C1_PPM_SHA256"):
+        line = next(l for l in src.splitlines() if l.startswith(name + " = "))
+        exec(line, consts)
+    W, H, spp, depth, aspect = po.cli_dims(consts["C1_ARGV"])
+    o = po.Oracle()
+    o.random_scene()
+    _, u8, seg = o.render_rows(po.stock_camera(aspect), W, H, spp, depth)
+    assert seg == consts["C1_RAYS"]
+    assert hashlib.sha256(po.ppm_bytes(u8)).hexdigest() == consts["C1_PPM_SHA256"] == HASHES[" ".join(consts["C1_ARGV"])]
+
+
 def test_oracle_scene_is_reference_scene(stock_scene_golden):
     o = po.Oracle()
     assert o.random_scene() == 484

@@ -50,6 +50,7 @@ def harness():
     h.ref_random_scene.argtypes = [fp] * 10 + [ip]
     h.ref_camera.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
     h.ref_list_hit.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_uint64, C.c_float, C.c_float, up, ip, fp]
+    h.ref_nested_list_hit.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, fp, C.c_uint64, C.c_float, C.c_float, up, ip, fp]
     h.ref_sphere_hit.argtypes = [fp, fp, fp, C.c_uint64, C.c_float, C.c_float, fp]
     h.ref_sample.argtypes = [C.c_int, C.c_uint64, fp]
     h.ref_hit_and_scatter.argtypes = [fp, fp, fp, fp, C.c_uint64, C.c_float, C.c_float, fp, fp]
@@ -324,6 +325,37 @@ def golden_image(W=120, H=80, parts=8, spp_part=250, depth=50):
     print("golden image", W, H, spp, "segments/sample %.4f" % (segs / (W * H * spp)))
 
 
+def golden_nested():
+    """A user scene (not random_scene) in NESTED reference HittableLists (ref_nested_list_hit) with the reference's
+    (hit, index, t) for random, tangent and tie rays: what a flatten of nested lists must reproduce through the HIP path."""
+    h = harness()
+    rng = np.random.default_rng(77)
+    n = 150
+    s = {"cx": rng.uniform(-6, 6, n).astype(np.float32), "cy": rng.uniform(-2, 3, n).astype(np.float32), "cz": rng.uniform(-14, -2, n).astype(np.float32),
+         "radius": np.exp(rng.uniform(np.log(0.15), np.log(1.2), n)).astype(np.float32)}
+    s["cx"][10:14] = s["cx"][10]; s["cy"][10:14] = s["cy"][10]; s["cz"][10:14] = s["cz"][10]; s["radius"][10:14] = s["radius"][10]    # four copies: ties
+    s["cy"][64:96] = 0.3; s["radius"][64:96] = 0.25                                                                                     # 32 spheres sharing cy and r
+    m = 6000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-1, 1, (m, 3))
+    tgt = np.stack([rng.uniform(-7, 7, m), rng.uniform(-3, 4, m), rng.uniform(-15, -1, m)], 1)
+    rays[:, 3:6] = (tgt - rays[:, 0:3]) * rng.uniform(0.05, 2.0, (m, 1))
+    k = rng.integers(0, n, 2000)                                                       # tangent rays
+    c = np.stack([s["cx"][k], s["cy"][k], s["cz"][k]], 1).astype(np.float64)
+    o = rays[:2000, 0:3].astype(np.float64)
+    oc = c - o
+    perp = np.cross(oc, rng.normal(size=(2000, 3))); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    rays[:2000, 3:6] = (oc + perp * (s["radius"][k] * (1 + rng.choice([-1, 1], 2000) * 10.0 ** rng.uniform(-7, -2, 2000)))[:, None]).astype(np.float32)
+    out = {}
+    for nest in (0, 5):
+        hit = np.zeros(m, np.uint8); idx = np.zeros(m, np.int32); t = np.zeros(m, np.float32)
+        h.ref_nested_list_hit(n, s["cx"], s["cy"], s["cz"], s["radius"], nest, rays, m, 0.001, np.inf, hit, idx, t)
+        out["nest%d_hit" % nest] = hit; out["nest%d_index" % nest] = idx; out["nest%d_t" % nest] = t
+        print("nested", nest, "hits", int(hit.sum()), "distinct winners", len(np.unique(idx[idx >= 0])))
+    assert np.array_equal(out["nest0_index"], out["nest5_index"]) and np.array_equal(out["nest0_t"].view(np.uint32), out["nest5_t"].view(np.uint32))
+    np.savez_compressed(os.path.join(GOLD, "rays_nested.npz"), rays=rays, **s, **out)
+
+
 def _band_part(args):
     part, W, H, spp, depth, bands = args
     from oracle import pyoracle as po
@@ -358,6 +390,9 @@ def golden_bands(W=1200, H=800, parts=8, spp_part=250, depth=50, bands=BANDS_120
 
 
 if __name__ == "__main__":
+    if "--nested-only" in sys.argv:
+        golden_nested()
+        sys.exit(0)
     if "--bands-only" in sys.argv:
         golden_bands()
         sys.exit(0)
