@@ -70,8 +70,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs 
     __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
     if (threadIdx.x < sizeof(CameraDev) / sizeof(float))
         reinterpret_cast<float*>(&s_cam)[threadIdx.x] = reinterpret_cast<const float*>(&A.cam)[threadIdx.x];
+    // The grid's 35 parameters as well: as kernel arguments they are SGPRs that the grid walk keeps live through its
+    // loops, and the register allocator spilled 51 of them (some to scratch memory).
+    __shared__ GridDev s_grid;
+    if (GRID && threadIdx.x < sizeof(GridDev) / 4)
+        reinterpret_cast<uint32_t*>(&s_grid)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&A.grid)[threadIdx.x];
     const Intersector<LDS> isect = make_intersector<LDS>(A.scene, smem);      // ends with __syncthreads()
-    render_wave<LDS, GRID>(A, isect, &s_cam);
+    render_wave<LDS, GRID>(A, isect, &s_cam, &s_grid);
 }
 
 // accumulators -> fp32 sums, and clear them for the next frame.

@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned long long to_fixed_32_32(float f) {
 // needed once per pass, and as kernel arguments they sit in SGPRs that the register allocator spills to VGPR lanes
 // and reads back with v_readlane (VALU slots) in every pass; from LDS they cost six reads on the LDS pipe instead.
 template <bool LDS, bool GRID = false>
-__device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect, const CameraDev* cam) {
+__device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect, const CameraDev* cam, const GridDev* grid = nullptr) {
     const int lane = isect.lane;
     const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
     const unsigned long long t_begin = rtk_wall_clock();
@@ -171,7 +171,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         // ---- one segment: HittableList::hit (main.cpp:90) ----
         float t;
         int idx;
-        if (GRID) isect.closest_hit_grid(A.grid, ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
+        if (GRID) isect.closest_hit_grid(*grid, ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
         else isect.closest_hit(ray, alive, A.t_min, __builtin_inff(), t, idx, n_exact);
         ++wave_passes;
         RTK_STAT_ANY(lane, pass_sky_block, alive && idx < 0);

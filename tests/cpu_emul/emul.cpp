@@ -251,11 +251,11 @@ int emul_render_tiles(void* h, const float* cam22, const rtk_params* p, float* t
             run_lanes([&](int lane) {
                 if (lds) {
                     const Intersector<true> it = make_isect<true>(e, list.data(), nullptr, lane, nullptr, masks.data());
-                    if (accel) render_wave<true, true>(A, it, &A.cam);
+                    if (accel) render_wave<true, true>(A, it, &A.cam, &A.grid);
                     else render_wave<true, false>(A, it, &A.cam);
                 } else {
                     const Intersector<false> it = make_isect<false>(e, list.data(), nullptr, lane, stage.data());
-                    if (accel) render_wave<false, true>(A, it, &A.cam);
+                    if (accel) render_wave<false, true>(A, it, &A.cam, &A.grid);
                     else render_wave<false, false>(A, it, &A.cam);
                 }
             });
