@@ -165,6 +165,47 @@ inline RenderResult render_image(const Hittable& world, const Camera& camera, in
     return render_image_progressive(world, camera, image_width, image_height, samples_per_pixel, max_depth, 1, [](int, int) {}, seed, device, accel);
 }
 
+// The same frame on SEVERAL GPUs of one node from this one process (rtk_multi_*: interleaved tiles, one context and
+// stream per device, framebuffer gathered on devices[0] over RCCL, de-interleaved and quantised there): writes the P6
+// file like render_ppm.  The image is bit-identical to the single-device render for any device list.  Returns the
+// frame's counters summed over the devices (kernel_ms = the slowest device's kernel).
+inline rtk_stats render_ppm_multi(std::ostream& out, const Hittable& world, const Camera& camera, int image_width, int image_height,
+                                  int samples_per_pixel, int max_depth, uint64_t seed, const std::vector<int32_t>& devices, int accel = RTK_ACCEL_LIST) {
+    const FlatScene flat = flatten(world);
+    rtk_multi* m = nullptr;
+    const auto check = [&m](int status, const char* what) {
+        if (status == RTK_OK) return;
+        const std::string msg = std::string(what) + ": " + rtk_last_error();
+        if (m) rtk_multi_destroy(m);
+        throw std::runtime_error(msg);
+    };
+    check(rtk_multi_create(devices.data(), static_cast<int32_t>(devices.size()), &m), "rtk_multi_create");
+    check(rtk_multi_set_accel(m, accel), "rtk_multi_set_accel");
+    const rtk_scene view = flat.view();
+    check(rtk_multi_set_scene(m, &view), "rtk_multi_set_scene");
+    const rtk_camera cam = camera.export_fields();
+    rtk_params p{};
+    p.width = image_width;
+    p.height = image_height;
+    p.spp = samples_per_pixel;
+    p.max_depth = max_depth;
+    p.seed = seed;
+    p.t_min = 0.001f;
+    std::vector<uint8_t> bytes(static_cast<size_t>(image_width) * image_height * 3);
+    std::vector<rtk_stats> per(devices.size());
+    check(rtk_multi_render(m, &cam, &p, nullptr, bytes.data(), per.data()), "rtk_multi_render");
+    rtk_multi_destroy(m);
+    out << "P6\n" << image_width << ' ' << image_height << '\n' << 255 << '\n';
+    out.write(reinterpret_cast<const char*>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
+    rtk_stats st{};
+    for (const rtk_stats& d : per) {
+        st.rays += d.rays; st.samples += d.samples; st.sphere_tests += d.sphere_tests; st.exact_tests += d.exact_tests; st.lane_slots += d.lane_slots;
+        st.kernel_ms = d.kernel_ms > st.kernel_ms ? d.kernel_ms : st.kernel_ms;
+        st.frames = 1;
+    }
+    return st;
+}
+
 // The reference's whole output step (main.cpp:57-76) in one call: render, apply write_color_binary ON THE DEVICE
 // (rtk_render_u8: a quarter of the bytes cross PCIe) and write header + payload of the P6 file.  The bytes equal
 // write_ppm_binary(render_image(...)) for the same seed.  Returns the frame's counters.

@@ -123,7 +123,9 @@ int rtk_context_create(int device, rtk_context** out);
 void rtk_context_destroy(rtk_context* ctx);
 
 /* Use an existing HIP stream (a hipStream_t passed as void*) for all work of the context;
- * NULL selects the context's own stream.  For callers that own device memory, e.g. torch. */
+ * NULL selects the context's own stream.  For callers that own device memory, e.g. torch.
+ * A switch is ordered: work submitted to the new stream waits for what the context queued on the old one (its
+ * accumulators, packet queue and run table are shared by consecutive frames). */
 int rtk_context_set_stream(rtk_context* ctx, void* hip_stream);
 
 /* How the closest hit is found.  No counterpart in the reference, whose HittableList::hit (HittableList.hpp:30-42)
@@ -256,6 +258,27 @@ int rtk_sample_batch(rtk_context* ctx, int32_t kind, const float* u4, size_t n, 
 
 /* Block until everything queued on the context's stream has finished. */
 int rtk_synchronize(rtk_context* ctx);
+
+/* ---- One process, several GPUs ---------------------------------------------------------------------------------
+ * The C/C++ caller's way to use a whole node: what the 17-line loop nest of main.cpp:62-78 becomes when the image is
+ * sharded by interleaved tiles (rank r = devices[r] renders tiles i % n == r; one context and stream per device; the
+ * scene is replicated) and the framebuffer is gathered on devices[0] — RCCL send/recv in one group over communicators
+ * from ncclCommInitAll when the devices are distinct (librccl.so.1 is opened on demand; nothing is linked), device
+ * copies ordered by events when a device is listed more than once (several ranks on one GPU: a test arrangement) —
+ * de-interleaved there and copied to the host.  The image is bit-identical for every n (global-pixel RNG counters,
+ * integer sample sums).  No counterpart in the reference (single-threaded, no device).
+ * rtk_multi_render: p->rank / p->world_size are ignored; out_rgb_sum ([height][width][3] colour sums) and out_u8 (the
+ * write_color_binary bytes, Color.hpp:28-48) are HOST buffers, either may be NULL; per_device (n entries) may be NULL.
+ * (Python drives the same sharding with one process per GPU and torch.distributed: raytracinginoneweekend_amd/distributed.py.) */
+typedef struct rtk_multi rtk_multi;
+int rtk_multi_create(const int32_t* devices, int32_t n_devices, rtk_multi** out);
+void rtk_multi_destroy(rtk_multi* m);
+int rtk_multi_device_count(const rtk_multi* m);
+int rtk_multi_uses_rccl(const rtk_multi* m);
+int rtk_multi_set_accel(rtk_multi* m, int32_t mode);
+int rtk_multi_set_scene(rtk_multi* m, const rtk_scene* scene);
+int rtk_multi_render(rtk_multi* m, const rtk_camera* cam, const rtk_params* p, float* out_rgb_sum, uint8_t* out_u8,
+                     rtk_stats* per_device);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,8 @@ C_ABI_SYMBOLS = (
     "rtk_primary_rays", "rtk_philox_batch", "rtk_synchronize", "rtk_reset_stats", "rtk_get_stats",
     "rtk_run_schedule", "rtk_deinterleave_u8_device", "rtk_render_u8", "rtk_context_set_accel", "rtk_accel_in_use",
     "rtk_render_tiles_device_noalloc", "rtk_scene_layout", "rtk_sample_batch",
+    "rtk_multi_create", "rtk_multi_destroy", "rtk_multi_device_count", "rtk_multi_uses_rccl", "rtk_multi_set_accel", "rtk_multi_set_scene",
+    "rtk_multi_render",
 )
 ACCEL_LIST, ACCEL_GRID = 0, 1
 
@@ -104,6 +106,14 @@ def lib() -> C.CDLL:
         l.rtk_primary_rays.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, sz, vp]
         l.rtk_philox_batch.argtypes = [vp, u64, vp, sz, vp]
         l.rtk_sample_batch.argtypes = [vp, i32, vp, sz, vp]
+        l.rtk_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
+        l.rtk_multi_destroy.argtypes = [vp]
+        l.rtk_multi_destroy.restype = None
+        l.rtk_multi_device_count.argtypes = [vp]
+        l.rtk_multi_uses_rccl.argtypes = [vp]
+        l.rtk_multi_set_accel.argtypes = [vp, i32]
+        l.rtk_multi_set_scene.argtypes = [vp, C.POINTER(rtk_scene)]
+        l.rtk_multi_render.argtypes = [vp, C.POINTER(rtk_camera), C.POINTER(rtk_params), vp, vp, vp]
         l.rtk_synchronize.argtypes = [vp]
         l.rtk_reset_stats.argtypes = [vp]
         l.rtk_get_stats.argtypes = [vp, C.POINTER(rtk_stats)]
@@ -211,6 +221,58 @@ def make_params(W, H, spp, depth, seed=0, t_min=0.001, rank=0, world=1, tile_w=8
     return rtk_params(W, H, spp, depth, seed, t_min, rank, world, tile_w, tile_h, run_len, sample_offset)
 
 
+def _scene_struct(scene: dict):
+    """rtk_scene view of a scene dict -> (struct, arrays it points into: keep them alive for the call)."""
+    arrs = {k: np.ascontiguousarray(scene[k], np.float32) for k in SCENE_FIELDS[:10]}
+    arrs["mat_type"] = np.ascontiguousarray(scene["mat_type"], np.int32)
+    s = rtk_scene()
+    s.n = len(arrs["cx"])
+    for k in SCENE_FIELDS[:10]:
+        setattr(s, k, arrs[k].ctypes.data_as(C.POINTER(C.c_float)))
+    s.mat_type = arrs["mat_type"].ctypes.data_as(C.POINTER(C.c_int32))
+    return s, arrs
+
+
+class Multi:
+    """rtk_multi: one process driving several GPUs (ranks = devices, in order; a device may be listed more than once)."""
+
+    def __init__(self, devices):
+        self._l = lib()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _check(self._l.rtk_multi_create(arr, len(self.devices), C.byref(h)), "rtk_multi_create")
+        self._h = h
+        self._scene_keep = None
+
+    def close(self):
+        if self._h:
+            self._l.rtk_multi_destroy(self._h)
+            self._h = None
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._l.rtk_multi_uses_rccl(self._h))
+
+    def set_accel(self, mode: int):
+        _check(self._l.rtk_multi_set_accel(self._h, mode), "rtk_multi_set_accel")
+
+    def set_scene(self, scene: dict):
+        s, keep = _scene_struct(scene)
+        self._scene_keep = keep
+        _check(self._l.rtk_multi_set_scene(self._h, C.byref(s)), "rtk_multi_set_scene")
+
+    def render(self, cam22, W, H, spp, depth, seed=0, want_u8=False, t_min=0.001, tile_w=8, tile_h=8, run_len=0, sample_offset=0):
+        """-> (float32 [H, W, 3] colour sums, uint8 [H, W, 3] or None, list of per-device stats dicts)."""
+        out = np.zeros((H, W, 3), np.float32)
+        u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
+        st = (rtk_stats * len(self.devices))()
+        p = make_params(W, H, spp, depth, seed, t_min, 0, 1, tile_w, tile_h, run_len, sample_offset)
+        cam = _cam_struct(cam22)
+        _check(self._l.rtk_multi_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data, u8.ctypes.data if want_u8 else None, st), "rtk_multi_render")
+        return out, u8, [x.as_dict() for x in st]
+
+
 class Context:
     """rtk_context on one device."""
 
@@ -236,13 +298,7 @@ class Context:
         _check(self._l.rtk_context_set_stream(self._h, C.c_void_p(stream_handle)), "rtk_context_set_stream")
 
     def set_scene(self, scene: dict) -> None:
-        arrs = {k: np.ascontiguousarray(scene[k], np.float32) for k in SCENE_FIELDS[:10]}
-        arrs["mat_type"] = np.ascontiguousarray(scene["mat_type"], np.int32)
-        s = rtk_scene()
-        s.n = len(arrs["cx"])
-        for k in SCENE_FIELDS[:10]:
-            setattr(s, k, arrs[k].ctypes.data_as(C.POINTER(C.c_float)))
-        s.mat_type = arrs["mat_type"].ctypes.data_as(C.POINTER(C.c_int32))
+        s, _keep = _scene_struct(scene)
         _check(self._l.rtk_set_scene(self._h, C.byref(s)), "rtk_set_scene")
         self.n = s.n
 

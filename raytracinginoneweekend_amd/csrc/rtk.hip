@@ -7,6 +7,9 @@
 
 #include "../../include/rtk.h"
 
+#include <rccl/rccl.h>      // types and prototypes only: the library is opened on demand (rtk_multi_create), never linked
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -244,6 +247,7 @@ struct rtk_context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev3 = nullptr;
+    hipEvent_t ev_switch = nullptr;                  // orders a new stream behind the old one (rtk_context_set_stream)
     static constexpr int kEventPairs = 256;          // render-kernel brackets of the frames since rtk_reset_stats
     hipEvent_t kev[2 * kEventPairs] = {};
     int n_frames = 0;                                // frames since the last reset
@@ -377,6 +381,7 @@ int rtk_context_create(int device, rtk_context** out) {
         c->stream = c->own_stream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev3));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
         for (hipEvent_t& e : c->kev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(c->control.reserve(512));
         HIP_TRY(hipMemset(c->control.p, 0, 512));
@@ -399,6 +404,7 @@ void rtk_context_destroy(rtk_context* c) {
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
+    if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
     for (hipEvent_t e : c->kev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -407,7 +413,15 @@ void rtk_context_destroy(rtk_context* c) {
 
 int rtk_context_set_stream(rtk_context* c, void* hip_stream) {
     if (!c) return fail(RTK_ERR_BAD_ARG, "null context");
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    if (next != c->stream) {
+        // the context's buffers (accumulators, queue, run table) may still be in use by work queued on the old stream:
+        // whatever is submitted to the new stream from now on is ordered behind it
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipEventRecord(c->ev_switch, c->stream));
+        HIP_TRY(hipStreamWaitEvent(next, c->ev_switch, 0));
+        c->stream = next;
+    }
     return RTK_OK;
 }
 
@@ -891,6 +905,220 @@ int rtk_philox_batch(rtk_context* c, uint64_t seed, const uint32_t* ctr4, size_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out4, c->scratch_e.p, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTK_OK;
+}
+
+} // extern "C"
+
+// =================================================================================================
+// One process, several GPUs (rtk_multi_*): the C/C++ drop-in's way to use a whole node.
+// Rank r = devices[r] renders the tiles i % n == r with its own context and stream; the compact tile buffers are
+// gathered on rank 0 — RCCL send/recv inside one group when the devices are distinct (ncclCommInitAll, one
+// communicator per device, xGMI underneath), plain device copies ordered by events when a device is listed more than
+// once (a test arrangement: several ranks on one GPU) — and de-interleaved there.  No collective during rendering.
+// =================================================================================================
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
+
+static int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return RTK_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(RTK_ERR_HIP, "cannot open librccl.so.1 (needed to gather tiles from several GPUs): %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.GetErrorString)
+        return fail(RTK_ERR_HIP, "librccl.so.1 lacks a symbol librtk needs");
+    g_rccl = a;
+    return RTK_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                                   \
+    do {                                                                                                                 \
+        const ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != ncclSuccess) return fail(RTK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct rtk_multi {
+    std::vector<int> devices;
+    std::vector<rtk_context*> ctx;
+    std::vector<ncclComm_t> comms;          // one per rank when the devices are distinct (RCCL gather), else empty
+    std::vector<hipEvent_t> done;           // per rank: its tiles are rendered (the copy gather waits on these)
+    std::vector<DevBuf> tiles;              // per rank >= 1: its compact tile sums, on its device
+    DevBuf gathered, image, image_u8;       // on devices[0]
+    bool use_rccl = false;
+};
+
+extern "C" {
+
+void rtk_multi_destroy(rtk_multi* m) {
+    if (!m) return;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        if (!m->ctx[r]) continue;
+        (void)hipSetDevice(m->devices[r]);
+        (void)hipStreamSynchronize(m->ctx[r]->stream);
+        if (r < m->comms.size() && m->comms[r]) (void)g_rccl.CommDestroy(m->comms[r]);
+        if (r < m->done.size() && m->done[r]) (void)hipEventDestroy(m->done[r]);
+        if (r < m->tiles.size()) m->tiles[r].release();
+    }
+    if (!m->devices.empty()) {
+        (void)hipSetDevice(m->devices[0]);
+        m->gathered.release();
+        m->image.release();
+        m->image_u8.release();
+    }
+    for (rtk_context* c : m->ctx) rtk_context_destroy(c);
+    delete m;
+}
+
+int rtk_multi_create(const int32_t* devices, int32_t n, rtk_multi** out) {
+    if (!out) return fail(RTK_ERR_BAD_ARG, "rtk_multi_create: out is null");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return fail(RTK_ERR_BAD_ARG, "rtk_multi_create: %d devices", n);
+    rtk_multi* m = new (std::nothrow) rtk_multi();
+    if (!m) return fail(RTK_ERR_HIP, "out of host memory");
+    const auto init = [m, devices, n]() -> int {
+        bool distinct = true;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+        m->devices.assign(devices, devices + n);
+        m->ctx.assign(n, nullptr);
+        m->done.assign(n, nullptr);
+        m->tiles.resize(n);
+        for (int r = 0; r < n; ++r) {
+            if (int e = rtk_context_create(devices[r], &m->ctx[r])) return e;
+            HIP_TRY(hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming));
+        }
+        m->use_rccl = n > 1 && distinct;
+        if (m->use_rccl) {
+            if (int e = load_rccl()) return e;
+            m->comms.assign(n, nullptr);
+            RCCL_TRY(g_rccl.CommInitAll(m->comms.data(), n, m->devices.data()));
+        }
+        return RTK_OK;
+    };
+    if (const int e = init()) {
+        rtk_multi_destroy(m);
+        return e;
+    }
+    *out = m;
+    return RTK_OK;
+}
+
+int rtk_multi_device_count(const rtk_multi* m) { return m ? static_cast<int>(m->devices.size()) : 0; }
+int rtk_multi_uses_rccl(const rtk_multi* m) { return (m && m->use_rccl) ? 1 : 0; }
+
+int rtk_multi_set_accel(rtk_multi* m, int32_t mode) {
+    if (!m) return fail(RTK_ERR_BAD_ARG, "null rtk_multi");
+    for (rtk_context* c : m->ctx)
+        if (int e = rtk_context_set_accel(c, mode)) return e;
+    return RTK_OK;
+}
+
+int rtk_multi_set_scene(rtk_multi* m, const rtk_scene* scene) {
+    if (!m || !scene) return fail(RTK_ERR_BAD_ARG, "rtk_multi_set_scene: null argument");
+    for (rtk_context* c : m->ctx)            // the scene is tiny and read-only: replicated
+        if (int e = rtk_set_scene(c, scene)) return e;
+    return RTK_OK;
+}
+
+int rtk_multi_render(rtk_multi* m, const rtk_camera* cam, const rtk_params* p, float* out_rgb_sum, uint8_t* out_u8, rtk_stats* per_device) {
+    if (!m || !cam || !p || (!out_rgb_sum && !out_u8)) return fail(RTK_ERR_BAD_ARG, "rtk_multi_render: null argument");
+    if (out_u8 && p->sample_offset != 0) return fail(RTK_ERR_BAD_ARG, "rtk_multi_render quantises a complete frame: sample_offset must be 0 for the 8-bit output");
+    int tw, th;
+    if (int e = norm_tiles(p, tw, th)) return e;
+    if (p->width < 2 || p->height < 2) return fail(RTK_ERR_BAD_ARG, "image %d x %d: the reference divides by (W-1) and (H-1), main.cpp:69-70", p->width, p->height);
+    const int n = static_cast<int>(m->devices.size());
+    const int64_t tprp = rtk_local_tile_count(p->width, p->height, tw, th, 0, n);        // rank 0 owns the most tiles
+    const size_t slice = static_cast<size_t>(tprp) * kTilePixels * 3;                     // floats per rank in the gather buffer
+    const size_t np = static_cast<size_t>(p->width) * p->height;
+    rtk_context* root = m->ctx[0];
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if (slice * n * sizeof(float) > m->gathered.cap) {
+        HIP_TRY(hipStreamSynchronize(root->stream));
+        HIP_TRY(m->gathered.reserve(slice * n * sizeof(float)));
+        HIP_TRY(hipMemset(m->gathered.p, 0, m->gathered.cap));      // tiles a rank does not own (padding of the last group) stay 0
+    }
+    HIP_TRY(m->image.reserve(np * 3 * sizeof(float)));
+    if (out_u8) HIP_TRY(m->image_u8.reserve(np * 3));
+    float* gathered = static_cast<float*>(m->gathered.p);
+    // 1. every rank renders its tiles on its own device and stream (asynchronous: the kernels of all devices overlap)
+    for (int r = 0; r < n; ++r) {
+        HIP_TRY(hipSetDevice(m->devices[r]));
+        float* dst = gathered;
+        if (r > 0) {
+            if (slice * sizeof(float) > m->tiles[r].cap) {
+                HIP_TRY(hipStreamSynchronize(m->ctx[r]->stream));
+                HIP_TRY(m->tiles[r].reserve(slice * sizeof(float)));
+                HIP_TRY(hipMemset(m->tiles[r].p, 0, m->tiles[r].cap));
+            }
+            dst = static_cast<float*>(m->tiles[r].p);
+        }
+        rtk_params q = *p;
+        q.rank = r;
+        q.world_size = n;
+        if (per_device)
+            if (int e = rtk_reset_stats(m->ctx[r])) return e;
+        if (int e = rtk_render_tiles_device(m->ctx[r], cam, &q, dst, nullptr)) return e;
+        HIP_TRY(hipEventRecord(m->done[r], m->ctx[r]->stream));
+    }
+    // 2. gather on rank 0: one RCCL group of sends and receives, or device copies when ranks share a device
+    if (n > 1) {
+        if (m->use_rccl) {
+            RCCL_TRY(g_rccl.GroupStart());
+            for (int r = 1; r < n; ++r) {
+                HIP_TRY(hipSetDevice(m->devices[r]));
+                RCCL_TRY(g_rccl.Send(m->tiles[r].p, slice, ncclFloat, 0, m->comms[r], m->ctx[r]->stream));
+                HIP_TRY(hipSetDevice(m->devices[0]));
+                RCCL_TRY(g_rccl.Recv(gathered + static_cast<size_t>(r) * slice, slice, ncclFloat, r, m->comms[0], root->stream));
+            }
+            RCCL_TRY(g_rccl.GroupEnd());
+        } else {
+            HIP_TRY(hipSetDevice(m->devices[0]));
+            for (int r = 1; r < n; ++r) {
+                HIP_TRY(hipStreamWaitEvent(root->stream, m->done[r], 0));
+                HIP_TRY(hipMemcpyAsync(gathered + static_cast<size_t>(r) * slice, m->tiles[r].p, slice * sizeof(float), hipMemcpyDeviceToDevice, root->stream));
+            }
+        }
+    }
+    // 3. scanline order (and the reference's bytes) on rank 0, then to the host
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    rtk_params q = *p;
+    q.rank = 0;
+    q.world_size = n;
+    if (int e = rtk_deinterleave_device(root, gathered, tprp, &q, static_cast<float*>(m->image.p))) return e;
+    if (out_u8) {
+        if (int e = rtk_quantise_device(root, static_cast<const float*>(m->image.p), static_cast<int64_t>(np), p->spp, static_cast<uint8_t*>(m->image_u8.p))) return e;
+        HIP_TRY(hipMemcpyAsync(out_u8, m->image_u8.p, np * 3, hipMemcpyDeviceToHost, root->stream));
+    }
+    if (out_rgb_sum) HIP_TRY(hipMemcpyAsync(out_rgb_sum, m->image.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    for (int r = 0; r < n; ++r) {
+        HIP_TRY(hipSetDevice(m->devices[r]));
+        if (per_device) {
+            if (int e = rtk_get_stats(m->ctx[r], &per_device[r])) return e;      // synchronises rank r's stream
+        } else {
+            HIP_TRY(hipStreamSynchronize(m->ctx[r]->stream));
+        }
+    }
     return RTK_OK;
 }
 

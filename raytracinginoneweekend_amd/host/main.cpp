@@ -3,7 +3,9 @@
 // in P6 format, same progress/timing lines on stderr — with the "Image Generation" scope executed
 // on an MI355X through librtk.so instead of the CPU loops.
 //
-// Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index, a 7th the number of
+// Extra, optional: a 5th argument is the RNG seed (default 0), a 6th the HIP device index — or a comma-separated LIST of
+// devices ("0,1,2,3,4,5,6,7"): the image is then sharded by interleaved tiles over those GPUs from this one process and
+// gathered over RCCL (rtk_multi_*; same bytes as on one device) —, a 7th the number of
 // progressive passes the samples are split into (default 1; progress is reported after each pass), an 8th selects how
 // the closest hit is found: 0 = the reference's list walk (default), 1 = uniform grid (same image, fewer sphere tests).
 #include "MathUtils.hpp"
@@ -19,6 +21,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <vector>
 
 int main(int argc, char** argv) {
     // Image (main.cpp:23-41)
@@ -34,7 +37,18 @@ int main(int argc, char** argv) {
     const int samples_per_pixel = argc > 3 ? static_cast<int>(std::stoll(argv[3])) : 100;
     const int max_depth = argc > 4 ? static_cast<int>(std::stoll(argv[4])) : 50;
     const uint64_t seed = argc > 5 ? std::stoull(argv[5]) : 0;
-    const int device = argc > 6 ? static_cast<int>(std::stoll(argv[6])) : 0;
+    std::vector<int32_t> devices;
+    if (argc > 6) {
+        const std::string list = argv[6];
+        for (size_t pos = 0; pos <= list.size();) {
+            const size_t comma = list.find(',', pos);
+            devices.push_back(static_cast<int32_t>(std::stoll(list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos))));
+            if (comma == std::string::npos) break;
+            pos = comma + 1;
+        }
+    }
+    if (devices.empty()) devices.push_back(0);
+    const int device = devices[0];
     const int batches = argc > 7 ? static_cast<int>(std::stoll(argv[7])) : 1;
     const int accel = argc > 8 ? static_cast<int>(std::stoll(argv[8])) : RTK_ACCEL_LIST;
 
@@ -48,7 +62,9 @@ int main(int argc, char** argv) {
         {
             PROFILE_LOG_SCOPE("Image Generation");
             std::cerr << "\rScanlines remaining: " << image_height - 1 << ' ' << std::flush;
-            if (batches <= 1) {
+            if (devices.size() > 1) {
+                stats = rtiow::render_ppm_multi(bin_file, world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, devices, accel);
+            } else if (batches <= 1) {
                 // one pass: gamma and quantisation run on the device, the file is one write
                 stats = rtiow::render_ppm(bin_file, world, camera, image_width, image_height, samples_per_pixel, max_depth, seed, device, accel);
             } else {

@@ -90,3 +90,13 @@ def test_built_library_is_not_older_than_its_sources():
     lib_time = os.path.getmtime(rt.LIB_PATH)
     stale = [os.path.basename(s) for s in srcs if os.path.getmtime(s) > lib_time]
     assert not stale, "rebuild librtk.so (python -m raytracinginoneweekend_amd.build): newer sources %s" % stale
+
+
+def test_rccl_library_offers_what_rtk_multi_opens_on_demand():
+    """rtk_multi_create (distinct devices) dlopens librccl.so.1 and resolves these symbols; nothing is linked."""
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", rt.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed
+    l = C.CDLL("librccl.so.1")
+    for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
+        assert hasattr(l, name), name
