@@ -12,6 +12,9 @@
 #include "rtk.h"
 
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <memory>
 #include <ostream>
 #include <stdexcept>
@@ -99,6 +102,7 @@ inline void write_ppm_binary(std::ostream& out, int image_width, int image_heigh
 struct RenderResult {
     std::vector<float> rgb_sum;   // [height][width][3], row 0 = top image row
     rtk_stats stats{};
+    int passes_done = 0;          // progressive renders: passes completed so far (== batches when the frame is finished)
 };
 
 // GPU render of `world` seen by `camera`: what main.cpp:64-76 computes, as per-pixel colour sums.
@@ -106,10 +110,47 @@ struct RenderResult {
 // added on the host in fp32); `progress(samples_done, samples_total)` is called after every pass — the analogue of
 // the reference's per-scanline progress line (main.cpp:65), which has no meaning on a device that renders all
 // scanlines at once.  Throws std::runtime_error with rtk_last_error() on failure (there is no CPU fallback).
+//
+// Resumable: with a `checkpoint_path` the running sums and the number of passes done are written to that file after
+// every pass (to a temporary first, then renamed), and a later call with the same path, image size, spp, depth, seed
+// and pass count CONTINUES after the last completed pass instead of starting over — the reference streams pixels to
+// its output and loses everything when interrupted (main.cpp:74).  The finished frame has the bits of an
+// uninterrupted one (same passes, same fp32 additions in the same order).  `max_passes_this_call` > 0 stops early
+// (what an interruption looks like to the next call); RenderResult::passes_done tells how far the frame is.
+struct ProgressiveCheckpoint {
+    // file layout: this header, then width * height * 3 floats
+    char magic[8];               // "RTKCKPT1"
+    int32_t width, height, spp, max_depth, batches, passes_done;
+    uint64_t seed;
+    uint64_t rays, samples;
+};
+
+inline bool load_checkpoint(const std::string& path, ProgressiveCheckpoint& h, std::vector<float>& sums) {
+    std::ifstream in(path, std::ios_base::binary);
+    if (!in) return false;
+    in.read(reinterpret_cast<char*>(&h), sizeof h);
+    if (!in || std::memcmp(h.magic, "RTKCKPT1", 8) != 0 || h.width <= 0 || h.height <= 0) return false;
+    sums.resize(static_cast<size_t>(h.width) * h.height * 3);
+    in.read(reinterpret_cast<char*>(sums.data()), static_cast<std::streamsize>(sums.size() * sizeof(float)));
+    return static_cast<bool>(in);
+}
+
+inline void save_checkpoint(const std::string& path, const ProgressiveCheckpoint& h, const std::vector<float>& sums) {
+    const std::string tmp = path + ".tmp";
+    {
+        std::ofstream out(tmp, std::ios_base::binary | std::ios_base::trunc);
+        out.write(reinterpret_cast<const char*>(&h), sizeof h);
+        out.write(reinterpret_cast<const char*>(sums.data()), static_cast<std::streamsize>(sums.size() * sizeof(float)));
+        if (!out) throw std::runtime_error("cannot write checkpoint " + tmp);
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename checkpoint to " + path);
+}
+
 template <class Progress>
 inline RenderResult render_image_progressive(const Hittable& world, const Camera& camera, int image_width, int image_height,
                                              int samples_per_pixel, int max_depth, int batches, Progress&& progress, uint64_t seed = 0,
-                                             int device = 0, int accel = RTK_ACCEL_LIST) {
+                                             int device = 0, int accel = RTK_ACCEL_LIST, const std::string& checkpoint_path = std::string(),
+                                             int max_passes_this_call = 0) {
     const FlatScene flat = flatten(world);
     rtk_context* ctx = nullptr;
     const auto check = [&ctx](int status, const char* what) {
@@ -129,8 +170,23 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
     std::vector<float> pass(n);
     if (batches < 1) batches = 1;
     if (batches > samples_per_pixel) batches = samples_per_pixel > 0 ? samples_per_pixel : 1;
-    int done = 0;
-    for (int b = 0; b < batches; ++b) {
+    int done = 0, first_pass = 0;
+    if (!checkpoint_path.empty()) {
+        ProgressiveCheckpoint h{};
+        std::vector<float> sums;
+        if (load_checkpoint(checkpoint_path, h, sums) && h.width == image_width && h.height == image_height && h.spp == samples_per_pixel &&
+            h.max_depth == max_depth && h.batches == batches && h.seed == seed && h.passes_done > 0 && h.passes_done <= batches) {
+            out.rgb_sum = sums;
+            out.stats.rays = h.rays;
+            out.stats.samples = h.samples;
+            first_pass = h.passes_done;
+            for (int b = 0; b < first_pass; ++b) done += (samples_per_pixel - done) / (batches - b);
+            progress(done, samples_per_pixel);
+        }
+    }
+    out.passes_done = first_pass;
+    for (int b = first_pass; b < batches; ++b) {
+        if (max_passes_this_call > 0 && b - first_pass >= max_passes_this_call) break;
         const int count = (samples_per_pixel - done) / (batches - b);
         rtk_params p{};
         p.width = image_width;
@@ -142,9 +198,8 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
         p.world_size = 1;
         p.sample_offset = done;
         rtk_stats st{};
-        check(rtk_render(ctx, &cam, &p, batches == 1 ? out.rgb_sum.data() : pass.data(), &st), "rtk_render");
-        if (batches > 1)
-            for (size_t i = 0; i < n; ++i) out.rgb_sum[i] += pass[i];
+        check(rtk_render(ctx, &cam, &p, pass.data(), &st), "rtk_render");
+        for (size_t i = 0; i < n; ++i) out.rgb_sum[i] += pass[i];
         out.stats.rays += st.rays;
         out.stats.samples += st.samples;
         out.stats.sphere_tests += st.sphere_tests;
@@ -154,6 +209,14 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
         out.stats.total_ms += st.total_ms;
         out.stats.frames += 1;
         done += count;
+        out.passes_done = b + 1;
+        if (!checkpoint_path.empty()) {
+            ProgressiveCheckpoint h{};
+            std::memcpy(h.magic, "RTKCKPT1", 8);
+            h.width = image_width; h.height = image_height; h.spp = samples_per_pixel; h.max_depth = max_depth; h.batches = batches;
+            h.passes_done = b + 1; h.seed = seed; h.rays = out.stats.rays; h.samples = out.stats.samples;
+            save_checkpoint(checkpoint_path, h, out.rgb_sum);
+        }
         progress(done, samples_per_pixel);
     }
     rtk_context_destroy(ctx);

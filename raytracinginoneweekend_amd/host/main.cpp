@@ -8,6 +8,9 @@
 // gathered over RCCL (rtk_multi_*; same bytes as on one device) —, a 7th the number of
 // progressive passes the samples are split into (default 1; progress is reported after each pass), an 8th selects how
 // the closest hit is found: 0 = the reference's list walk (default), 1 = uniform grid (same image, fewer sphere tests).
+// A 9th argument names a checkpoint file: with more than one pass the running sums are saved there after every pass and a
+// later run with the same arguments resumes after the last completed pass (a 10th argument stops this run after that
+// many passes: exit status 3, no image yet).
 #include "MathUtils.hpp"
 
 #include "Camera.hpp"
@@ -51,6 +54,8 @@ int main(int argc, char** argv) {
     const int device = devices[0];
     const int batches = argc > 7 ? static_cast<int>(std::stoll(argv[7])) : 1;
     const int accel = argc > 8 ? static_cast<int>(std::stoll(argv[8])) : RTK_ACCEL_LIST;
+    const std::string checkpoint = argc > 9 ? argv[9] : "";
+    const int max_passes = argc > 10 ? static_cast<int>(std::stoll(argv[10])) : 0;
 
     // World and camera (main.cpp:45-54)
     HittableList world = random_scene();
@@ -70,7 +75,12 @@ int main(int argc, char** argv) {
             } else {
                 const rtiow::RenderResult frame = rtiow::render_image_progressive(
                     world, camera, image_width, image_height, samples_per_pixel, max_depth, batches,
-                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; }, seed, device, accel);
+                    [](int done, int total) { std::cerr << "\rSamples remaining: " << total - done << ' ' << std::flush; }, seed, device, accel, checkpoint,
+                    max_passes);
+                if (frame.passes_done < batches) {
+                    std::cerr << "\nstopped after pass " << frame.passes_done << " of " << batches << "; resume with the same arguments\n";
+                    return 3;
+                }
                 rtiow::write_ppm_binary(bin_file, image_width, image_height, frame.rgb_sum.data(), samples_per_pixel);
                 stats = frame.stats;
             }

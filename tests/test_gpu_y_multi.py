@@ -59,3 +59,25 @@ def test_drop_in_executable_takes_a_device_list(gpu_ctx, tmp_path):
     got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
     want, _ = gpu_ctx.render_u8(rt.stock_camera(float(np.float32(W) / np.float32(H))), W, H, spp, depth, seed=0)
     assert np.array_equal(got, want)
+
+
+def test_drop_in_executable_resumes_from_its_checkpoint(tmp_path):
+    """a progressive render interrupted after 2 of 5 passes and resumed by a NEW process writes the same
+    file as the uninterrupted run (same passes, same fp32 additions in the same order)."""
+    exe = os.path.join(os.path.dirname(rt.__file__), "host", "rtiow_amd")
+    args = ["64", "42", "20", "50", "7", "0", "5", "0"]
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([exe, *args], cwd=a, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    whole = (a / "image_binary.ppm").read_bytes()
+    r = subprocess.run([exe, *args, "frame.ckpt", "2"], cwd=b, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "stopped after pass 2 of 5" in r.stderr and (b / "frame.ckpt").exists()
+    r = subprocess.run([exe, *args, "frame.ckpt", "1"], cwd=b, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "stopped after pass 3 of 5" in r.stderr
+    r = subprocess.run([exe, *args, "frame.ckpt"], cwd=b, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (b / "image_binary.ppm").read_bytes() == whole
+    # a checkpoint of other parameters is ignored: the frame starts over and still ends in the same file
+    r = subprocess.run([exe, "64", "42", "20", "50", "8", "0", "5", "0", "frame.ckpt"], cwd=b, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and (b / "image_binary.ppm").read_bytes() != whole
