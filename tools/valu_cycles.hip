@@ -96,11 +96,41 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     X(v_add_f64, asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(db)))                                                \
     X(v_fma_f64, asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(d[j]) : "v"(db)))                                            \
     X(s_nop_0, asm volatile("s_nop 0"))                                                                                      \
+    X(v_fma_f32_clamp, asm volatile("v_fma_f32 %0, -%1, %2, %0 clamp" : "+v"(a[j]) : "v"(b), "v"(c)))                         \
+    X(v_fma_f32_double_add, asm volatile("v_fma_f32 %0, %0, 2.0, %1" : "+v"(a[j]) : "v"(b)))                                 \
+    X(v_cvt_u32_f32, asm volatile("v_cvt_u32_f32_e32 %0, %0" : "+v"(a[j])))                                                  \
+    X(mix_class_7, MIXC7(j))                                                                                                 \
+    X(mix_class_clamp_7, MIXCC(j))                                                                                           \
+    X(mix_class_sgpr_7, MIXCS(j))                                                                                            \
+    X(mix_class_sgpr_alignbit_7, MIXCSA(j))                                                                                  \
     X(mix_form1_9, MIXF1(j))                                                                                                 \
     X(mix_7fma_cmp, MIX7C(j))                                                                                                \
     X(mix_f16pair_10, MIXF2(j))
 
-// one filter test, form 1 as shipped: 8 FMA + alignbit (9 instructions)
+// one class-word filter test as shipped in r02-c: 6 FMA + alignbit (7 instructions)
+#define MIXC7(j)                                                                                                                   \
+    asm volatile("v_fma_f32 %0, %2, %3, %0\n v_fma_f32 %1, %3, %2, %1\n v_fma_f32 %0, %3, %3, %0\n v_fma_f32 %1, %2, %2, %1\n"     \
+                 "v_fma_f32 %0, %0, %0, %3\n v_fma_f32 %0, %1, %1, %0\n"                                                           \
+                 "v_alignbit_b32 %4, %4, %0, 31"                                                                                   \
+                 : "+v"(a[j]), "+v"(a[(j + 4) & 7]), "+v"(b), "+v"(c), "+v"(m))
+// candidate: the sign collected by a clamped FMA (exactly 0 or 1) and a doubling FMA instead of the funnel shift (7 FMA-rate instructions)
+#define MIXCC(j)                                                                                                                   \
+    asm volatile("v_fma_f32 %0, %2, %3, %0\n v_fma_f32 %1, %3, %2, %1\n v_fma_f32 %0, %3, %3, %0\n v_fma_f32 %1, %2, %2, %1\n"     \
+                 "v_fma_f32 %0, -%0, %0, %3\n v_fma_f32 %0, -%1, %1, %0 clamp\n"                                                   \
+                 "v_fma_f32 %4, %4, 2.0, %0"                                                                                       \
+                 : "+v"(a[j]), "+v"(a[(j + 4) & 7]), "+v"(b), "+v"(c), "+v"(tmp))
+// the clamp form with the sphere's operands in SGPRs (a different pair for every test), as the scalar-load filter issues it
+#define MIXCS(j)                                                                                                                   \
+    asm volatile("v_fma_f32 %0, %4, %2, %3\n v_fmac_f32_e32 %0, %5, %3\n v_fma_f32 %1, %4, %3, %2\n v_fmac_f32_e32 %1, %5, %2\n"     \
+                 "v_fma_f32 %0, -%0, %0, %6\n v_fma_f32 %0, -%1, %1, %0 clamp\n"                                                   \
+                 "v_fmac_f32_e32 %7, 2.0, %0"                                                                                      \
+                 : "+v"(a[j]), "+v"(a[(j + 4) & 7]), "+v"(b), "+v"(c) : "s"(sv[2 * j]), "s"(sv[2 * j + 1]), "s"(sb), "v"(tmp))
+#define MIXCSA(j)                                                                                                                  \
+    asm volatile("v_fma_f32 %0, %4, %2, %3\n v_fmac_f32_e32 %0, %5, %3\n v_fma_f32 %1, %4, %3, %2\n v_fmac_f32_e32 %1, %5, %2\n"     \
+                 "v_fma_f32 %0, -%0, %0, %6\n v_fma_f32 %0, %1, %1, -%0\n"                                                         \
+                 "v_alignbit_b32 %7, %7, %0, 31"                                                                                   \
+                 : "+v"(a[j]), "+v"(a[(j + 4) & 7]), "+v"(b), "+v"(c) : "s"(sv[2 * j]), "s"(sv[2 * j + 1]), "s"(sb), "v"(m))
+// one filter test, form 1 as shipped in round 1: 8 FMA + alignbit (9 instructions)
 #define MIXF1(j)                                                                                                                   \
     asm volatile("v_fma_f32 %0, %2, %3, %0\n v_fma_f32 %1, %3, %2, %1\n v_fma_f32 %0, %3, %3, %0\n v_fma_f32 %1, %2, %2, %1\n"     \
                  "v_fma_f32 %0, %2, %2, %0\n v_fma_f32 %1, %3, %3, %1\n v_fma_f32 %0, %0, %0, %3\n v_fma_f32 %0, %1, %1, %0\n"     \
@@ -129,7 +159,7 @@ static const char* kNames[N_OPS] = {
     OPS(X)
 #undef X
 };
-static int instr_per_body(int op) { return op == OP_mix_form1_9 ? 9 : op == OP_mix_7fma_cmp ? 8 : op == OP_mix_f16pair_10 ? 10 : 1; }
+static int instr_per_body(int op) { return op == OP_mix_form1_9 ? 9 : op == OP_mix_class_7 ? 7 : op == OP_mix_class_clamp_7 ? 7 : op == OP_mix_class_sgpr_7 ? 7 : op == OP_mix_class_sgpr_alignbit_7 ? 7 : op == OP_mix_7fma_cmp ? 8 : op == OP_mix_f16pair_10 ? 10 : 1; }
 
 template <int OP>
 __global__ __launch_bounds__(1024) void cyc_kernel(float* out, unsigned long long* cycles, int iters, float seed_s) {
@@ -144,6 +174,9 @@ __global__ __launch_bounds__(1024) void cyc_kernel(float* out, unsigned long lon
     const f2 pb = {b, b}, pc = {c, c};
     const double db = 1.0 + threadIdx.x * 1e-12;
     const float sb = __builtin_amdgcn_readfirstlane(seed_s);
+    float sv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sv[j] = __builtin_amdgcn_readfirstlane(seed_s + 0.01f * j);
     unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -174,6 +207,16 @@ __global__ __launch_bounds__(1024) void cyc_kernel(float* out, unsigned long lon
     const size_t gid = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
     out[gid] = s;
     if ((threadIdx.x & 63) == 0) cycles[gid >> 6] = t1 - t0;
+}
+
+// What the clamp output modifier makes of the values a filter test can produce (kernels run with DX10_CLAMP set: NaN -> 0).
+__global__ void clamp_semantics(const float* in, float* out, int n) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        float r;
+        asm volatile("v_fma_f32 %0, %1, 1.0, 0 clamp" : "=v"(r) : "v"(in[i]));
+        out[i] = r;
+    }
 }
 
 static int g_threads = 256, g_lds = 0;
@@ -221,6 +264,20 @@ int main(int argc, char** argv) {
     g_lds = blocks_per_cu == 1 ? 96 * 1024 : 64 * 1024;
     const int grid = n_cu * blocks_per_cu;
     const size_t n_threads = static_cast<size_t>(grid) * g_threads;
+    {
+        const float in[10] = {__builtin_nanf(""), __builtin_inff(), -__builtin_inff(), 0.5f, -0.0f, 2.0f, 1e-40f, -1e-40f, 1.0f, 0x1p-126f};
+        float *d_in = nullptr, *d_res = nullptr, res[10];
+        CHECK(hipMalloc(&d_in, sizeof(in)));
+        CHECK(hipMalloc(&d_res, sizeof(in)));
+        CHECK(hipMemcpy(d_in, in, sizeof(in), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(clamp_semantics, dim3(1), dim3(64), 0, 0, d_in, d_res, 10);
+        CHECK(hipMemcpy(res, d_res, sizeof(in), hipMemcpyDeviceToHost));
+        std::printf("clamp(x):");
+        for (int i = 0; i < 10; ++i) std::printf("  %g -> %g", in[i], res[i]);
+        std::printf("\n");
+        CHECK(hipFree(d_in));
+        CHECK(hipFree(d_res));
+    }
     float* d_out = nullptr;
     unsigned long long* d_cyc = nullptr;
     CHECK(hipMalloc(&d_out, n_threads * sizeof(float)));
