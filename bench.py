@@ -43,7 +43,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-KERNEL_TAG = "r02-c (projection filter on a horizontal basis, 8-byte class records for words sharing cy and radius, candidate mask words kept in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
+KERNEL_TAG = "r02-d (projection filter: the two projections of 32 spheres x 32 rays as one bf16 MFMA each from exact three-part splits, squares/clamp/bit accumulation in 3 fp32 FMAs per test; candidate mask words in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
 
 
 # BASELINE.json configs[0] — the reference's own CPU-runnable case: `400 225 10 50`.  The reference is deterministic
@@ -160,6 +160,14 @@ def main():
         for key in ("rays", "samples", "sphere_tests", "exact_tests", "lane_slots", "kernel_ms", "frames", "frames_timed"):
             st[key] += o[key]
 
+    # the kernel's drain share is a per-launch figure (min / max over the waves of everything since the last reset):
+    # one more frame, untimed, on cleared counters
+    for c in ctxs:
+        c.reset_stats()
+    step(args.steps)
+    fence()
+    drain_frac = ctx.get_stats().get("drain_frac")
+
     per_rank_ms = [st["kernel_ms"] / max(1, st["frames_timed"])]
     if world > 1:
         gathered = [None] * world
@@ -193,7 +201,8 @@ def main():
         headline = args.scene_k <= 0 and args.accel == "list"
         lay = ctx.scene_layout()
         n_class = 32 * lay["class_words"]
-        filt_valu = (7.0 * n_class + 8.0 * (n_spheres - n_class)) / n_spheres          # vector instructions per ray-sphere filter test
+        on_matrix_pipe = n_spheres <= 1024
+        filt_valu = 3.0 if on_matrix_pipe else 8.0                                      # vector instructions per ray-sphere filter test
         alg_bytes = args.width * args.height * 3 * (8 + 4) / world                       # per launch: one u64 accumulator + one fp32 sum per channel
         out = {
             "metric": "Mrays/s (whole node), final scene 1200x800 500spp" if headline else
@@ -211,12 +220,15 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_tag": KERNEL_TAG, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays, "per_rank_kernel_ms": per_rank_ms,
-                         "basis": "ALGORITHMIC flops (17 per ray-sphere test x spheres x rays, SURVEY.md §8d), not executed ones: the kernel runs a conservative "
-                                  "%.2f-instruction fp32 filter per test plus ~2 exact reference tests per ray; executed-fp32 fraction from counters: profiles/*_summary.md" % filt_valu,
+                         "basis": "ALGORITHMIC flops (17 per ray-sphere test x spheres x rays, SURVEY.md §8d) against the fp32 VECTOR peak, not executed ones: the kernel runs a conservative "
+                                  "filter per test (" + ("its two projections on the matrix pipe as split-bf16 products, 4 x v_mfma_f32_32x32x16_bf16 per 32 spheres x 64 rays, then 3 fp32 vector FMAs"
+                                                         if on_matrix_pipe else "8 fp32 vector instructions") +
+                                  ") plus ~2 exact reference tests per ray; executed-instruction counts from counters: profiles/*_summary.md",
+                         "filter_on_matrix_pipe": on_matrix_pipe,
                          "filter_valu_per_test": filt_valu, "class_words": lay["class_words"], "lds_bytes_per_workgroup": lay["lds_bytes_per_workgroup"],
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays),
-                         "drain_frac_last_frame": st.get("drain_frac")},
+                         "drain_frac_last_frame": drain_frac},
         }
         if args.accel == "grid":
             # the 17-flop-per-test model prices the list walk; with a grid the useful figure is tests per ray

@@ -15,7 +15,10 @@ HOST_CAPI = os.path.join(HERE, "librtiow_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact intersection stage and the shading arithmetic must round every fp32
 # operation separately, as the reference build does (rtk_device.hpp header comment).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: the matrix instructions of the filter write ordinary VGPRs (their results feed vector FMAs at
+# once; with accumulation registers every result would cost a v_accvgpr_read first).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _stale(target: str, sources) -> bool:

@@ -26,26 +26,28 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout.  LDS-resident scene: [filt_len] filt float4 | [npad / 32] word descriptors | [npad] exact float4 |
-// [4 waves][npad / 32][64] u32 candidate mask words.  Streamed scene: [4][kListCap][64] u16 candidate lists |
-// [4][kStageSpheres] float4 staging chunks, one per wave.
+// Dynamic LDS layout.  LDS-resident scene: [64 x npad / 32] float4 A fragments of the words' bf16 tiles | [npad / 32] word
+// descriptors | [n] exact float4 | [4 waves][npad / 32][64] u32 candidate mask words (the r^2 tables of general words
+// stay in global memory: two words of sixteen on the stock scene, and 40 KiB per workgroup is what four workgroups per
+// CU allow).  Streamed scene: [4][kListCap][64] u16 candidate lists | [4][kStageSpheres] float4 staging chunks, one per wave.
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {
-        const int nw = sc.npad / 32;
+        const int nw = sc.npad / 32, nt = nw * 64;
         float4* lf = reinterpret_cast<float4*>(p);
-        float4* lw = lf + sc.filt_len;
+        float4* lw = lf + nt;
         float4* le = lw + nw;
-        for (int i = threadIdx.x; i < sc.filt_len; i += blockDim.x) lf[i] = sc.filt[i];
+        for (int i = threadIdx.x; i < nt; i += blockDim.x) lf[i] = sc.filt[i];
         for (int i = threadIdx.x; i < nw; i += blockDim.x) lw[i] = sc.wdesc[i];
-        for (int i = threadIdx.x; i < sc.npad; i += blockDim.x) le[i] = sc.exact[i];
+        for (int i = threadIdx.x; i < sc.n; i += blockDim.x) le[i] = sc.exact[i];
         it.filt = lf;
+        it.tables = sc.filt;
         it.wdesc = lw;
         it.exact = le;
-        p += static_cast<size_t>(sc.filt_len + nw + sc.npad) * sizeof(float4);
+        p += static_cast<size_t>(nt + nw + sc.n) * sizeof(float4);
         it.masks = reinterpret_cast<uint32_t*>(p) + wave * (nw * kWave);
         it.list = nullptr;
     } else {
@@ -62,7 +64,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 }
 
 static size_t lds_bytes(bool lds, const SceneDev& sc) {
-    return lds ? static_cast<size_t>(sc.filt_len + sc.npad / 32 + sc.npad) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
+    return lds ? static_cast<size_t>(sc.npad / 32 * 64 + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
                : kWavesPerBlock * kStageSpheres * sizeof(float4) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
@@ -256,6 +258,8 @@ struct rtk_context {
     SceneDev scene = {};
     bool have_scene = false;
     DevBuf filt, wdesc, exact, mat0, mat1;
+    SceneDev scene_flat = {};   // the same scene in the streamed layout: what the kernels that do not keep it in LDS read (large scenes: == scene; small scenes under the grid)
+    DevBuf filt_flat;
     int class_words = 0;     // words of 32 spheres with 8-byte class records (rtk_scene_layout)
     uint64_t last_waves = 0; // wavefronts of the last render launch
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
@@ -399,7 +403,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->wdesc, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->filt_flat, &c->wdesc, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -463,6 +467,18 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
         HIP_TRY(c->wdesc.reserve(sizeof(float4) * ps.wdesc.size()));
         HIP_TRY(hipMemcpy(c->wdesc.p, ps.wdesc.data(), sizeof(float4) * ps.wdesc.size(), hipMemcpyHostToDevice));
         c->scene.wdesc = static_cast<const float4*>(c->wdesc.p);
+    }
+    c->scene_flat = c->scene;
+    if (compact) {
+        // the grid kernels do not keep the scene in LDS; their fallback for rays the grid cannot serve streams the list
+        PreparedScene flat;
+        prepare_scene(s, flat, false);
+        HIP_TRY(c->filt_flat.reserve(sizeof(float4) * flat.filt.size()));
+        HIP_TRY(hipMemcpy(c->filt_flat.p, flat.filt.data(), sizeof(float4) * flat.filt.size(), hipMemcpyHostToDevice));
+        c->scene_flat.filt = static_cast<const float4*>(c->filt_flat.p);
+        c->scene_flat.filt_len = static_cast<int32_t>(flat.filt.size());
+        c->scene_flat.wdesc = nullptr;
+        c->scene_flat.fb = flat.fb;
     }
     c->have_scene = true;
     c->h_cx.assign(s->cx, s->cx + n); c->h_cy.assign(s->cy, s->cy + n); c->h_cz.assign(s->cz, s->cz + n); c->h_radius.assign(s->radius, s->radius + n);
@@ -612,7 +628,7 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
     }
 
     RenderArgs A;
-    A.scene = c->scene;
+    A.scene = (use_lds(c) && !use_grid(c)) ? c->scene : c->scene_flat;
     std::memcpy(&A.cam, cam, sizeof(float) * 22);
     A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_depth = p->max_depth;
     A.sample_offset = static_cast<uint32_t>(p->sample_offset);
@@ -802,11 +818,11 @@ int rtk_intersect_batch_device(rtk_context* c, const float* d_rays, size_t n, fl
     const size_t cap = static_cast<size_t>(c->n_cu) * (bpc > 0 ? bpc : 1);
     if (grid > cap) grid = cap;
     if (accel)
-        hipLaunchKernelGGL((intersect_kernel<false, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
+        hipLaunchKernelGGL((intersect_kernel<false, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene_flat, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
     else if (lds)
         hipLaunchKernelGGL(intersect_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
     else
-        hipLaunchKernelGGL(intersect_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
+        hipLaunchKernelGGL(intersect_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, c->scene_flat, d_rays, n, t_min, t_max, d_hit, d_index, d_t, c->grid);
     HIP_TRY(hipGetLastError());
     return RTK_OK;
 }

@@ -21,6 +21,7 @@
 #ifndef RTK_HOST_EMULATION
 #define RTK_STAT(lane, name) ((void)0)
 #define RTK_STAT_ANY(lane, name, pred) ((void)0)
+#define RTK_STAT_EACH(name) ((void)0)
 #endif
 
 #ifndef RTK_LANES
@@ -113,15 +114,24 @@ struct FilterBounds {
     float c_max;     // max |C| + |r|
     float r_max2;    // max r^2
     float r_min;     // min |r|
+    float scale;     // S = 2^s: LDS-resident scenes scale the filter's basis by it and the r^2 terms by S^2 (rtk_scene_prep.hpp)
 };
 
 struct SceneDev {
-    // Filter operands, one record block per WORD of 32 consecutive list entries (list order is kept: the exact stage's
-    // tie rule depends on it).  A general word holds 32 float4 (cx, cy, cz, r^2 (1+k)); a CLASS word — all 32 spheres
-    // filterable with bit-identical cy and radius, which is what every small sphere of the reference's random_scene()
-    // is (main.cpp:124: centre (a + .9 rand, 0.2, b + .9 rand), radius 0.2) — holds 16 float4 = 32 x (cx, cz), and its
-    // shared cy and r^2 (1+k) sit in the word's descriptor: two of the eight FMAs of a test become per-ray constants.
-    // Pads never pass.  wdesc == nullptr: every word is general at offset 32 w (scenes streamed through LDS chunks).
+    // Filter operands, one block per WORD of 32 consecutive list entries (list order is kept: the exact stage's tie
+    // rule depends on it).
+    // Scenes of up to kMaxLdsSpheres spheres (wdesc != nullptr) — the projections run on the matrix pipe:
+    //   filt[64 w + l], w < npad / 32: lane l's 16-byte A fragment of word w for v_mfma_f32_32x32x16_bf16 — row
+    //   l & 31 of the word's 32 x 16 tile, k = 8 (l >> 5) ... + 7, eight bf16: the sphere's split coordinates
+    //   (kTileTerms below).  Row rho holds sphere tile_row_sphere(rho), chosen so that the results a lane receives
+    //   are 16 consecutive spheres.  After the tiles: one table of 2 x 16 r^2 terms (S^2 r^2 (1+k), in the order the
+    //   lanes of either half hold their results) per GENERAL word; a CLASS word — 32 filterable spheres with one
+    //   radius, which is what every small sphere of the reference's random_scene() is (main.cpp:124) — has the one
+    //   value in its descriptor.  Pads and always-candidates: zero rows, r^2 term -inf (the filter never passes them;
+    //   always-candidates come back through the descriptor's `always` bits).
+    //   wdesc[w] = (float4 index of the word's r^2 table, kind: 1 = class, always bits, S^2 r^2 (1+k) of a class word).
+    // Larger scenes (wdesc == nullptr), streamed through LDS chunks and filtered on the vector ALUs:
+    //   filt[i] = (cx, cy, cz, r^2 (1+k)), i < npad; pads -inf, always-candidates +inf.
     const float4* filt;   // [filt_len]
     const float4* exact;  // [npad] cx, cy, cz, r*r  (fl(r*r), Sphere3.hpp:35)
     const float4* mat0;   // [n] colour r, g, b, roughness
@@ -129,9 +139,51 @@ struct SceneDev {
     int32_t n;
     int32_t npad;         // n rounded up to a multiple of 32
     FilterBounds fb;
-    const float4* wdesc = nullptr;   // [npad / 32] x: offset into filt (int bits), y: 1 = class word (int bits), z: cy, w: r^2 (1+k)
+    const float4* wdesc = nullptr;   // [npad / 32]
     int32_t filt_len = 0;            // float4 entries of filt
 };
+
+// ---- the 32 x 16 bf16 tile of a word (A operand) and the matching ray vector (B operand) ----------------------------
+// A coordinate c is split into bf16 parts c = c1 + c2 + c3 (exact: 3 x 8 mantissa bits), a basis component e likewise;
+// the product c e is summed from the terms listed here (sphere part, ray part).  x and z: (1,1) (1,2) (2,1) (1,3)
+// (3,1); y: (1,1) (1,2) (2,1); the constant -o.e: 1 x (n1, n2, n3).  What is left out — (2,2) and beyond for x and z,
+// (1,3) (3,1) (2,2) and beyond for y — is below 2^-16 (1 + 2^-6) |c| |e| per product: part of the filter's delta.
+constexpr int kTileK = 16;
+// part (1..3) of the sphere's x, z, y coordinate — or the constant one (coordinate 3) — that row element k holds
+__host__ __device__ inline void tile_term(int k, int& coord, int& sphere_part, int& ray_part) {
+    const int sp5[5] = {1, 1, 2, 1, 3}, rp5[5] = {1, 2, 1, 3, 1};
+    if (k < 5) { coord = 0; sphere_part = sp5[k]; ray_part = rp5[k]; }
+    else if (k < 10) { coord = 2; sphere_part = sp5[k - 5]; ray_part = rp5[k - 5]; }
+    else if (k < 13) { coord = 1; sphere_part = sp5[k - 10]; ray_part = rp5[k - 10]; }
+    else { coord = 3; sphere_part = 1; ray_part = k - 12; }
+}
+// Result register reg (0..15) of a lane in half hf (lane >> 5) is row (reg & 3) + 8 (reg >> 2) + 4 hf of the tile.  The
+// filter accumulates even registers into one bit string and odd ones into another, so row rho holds this sphere of the
+// word: lanes of half hf receive spheres 16 hf .. 16 hf + 15, register 2 m + c sphere 16 hf + 8 c + m.
+__host__ __device__ inline int tile_row_sphere(int rho) {
+    const int hf = (rho >> 2) & 1, r = rho - 4 * hf, c = r & 1, m = 2 * (r >> 3) + ((r >> 1) & 1);
+    return 16 * hf + 8 * c + m;
+}
+// float -> bf16 bits, round to nearest even (finite inputs; inf stays inf), and back
+__host__ __device__ inline uint16_t bf16_rne(float v) {
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+__host__ __device__ inline float bf16_value(uint16_t b) {
+    const uint32_t u = static_cast<uint32_t>(b) << 16;
+    float v;
+    __builtin_memcpy(&v, &u, 4);
+    return v;
+}
+// v = p[0] + p[1] + p[2] in bf16 parts
+__host__ __device__ inline void bf16_split3(float v, uint16_t p[3]) {
+    p[0] = bf16_rne(v);
+    const float r1 = v - bf16_value(p[0]);
+    p[1] = bf16_rne(r1);
+    p[2] = bf16_rne(r1 - bf16_value(p[1]));
+}
 
 struct CameraDev {
     V3 origin, llc, horizontal, vertical, u, v, w;

@@ -69,8 +69,9 @@ struct GridDev {
 
 template <bool LDS>
 struct Intersector {
-    const float4* filt;    // LDS or global
+    const float4* filt;    // LDS == true: the words' A fragments in LDS; else SceneDev::filt in global memory
     const float4* wdesc = nullptr;   // LDS (with LDS == true) or null: word descriptors, SceneDev::wdesc
+    const float4* tables = nullptr;  // LDS == true: SceneDev::filt in global memory (the descriptors' offsets of the r^2 tables index it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // !LDS: this wave's candidate list in LDS: [kListCap][64]
     uint32_t* masks = nullptr;   // LDS: this wave's candidate mask words in LDS: [npad / 32][64]
@@ -113,14 +114,6 @@ struct Intersector {
         const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
         m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
     }
-    // The same for a sphere of a class word: k2 = cy e2.y - o.e2 and nr2 = -r^2 (1+k) are the word's per-ray constants.
-    static __device__ __forceinline__ void filter_class(const FilterRay& f, float k2, float nr2, float sx, float sz, uint32_t& m) {
-        const float p1 = fmaf(sz, f.e1z, fmaf(sx, f.e1x, f.ns1));
-        const float p2 = fmaf(sz, f.e2z, fmaf(sx, f.e2x, k2));
-        const float dd = fmaf(p2, p2, fmaf(p1, p1, nr2));
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
-    }
-
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
                                                 uint32_t& n_exact) const {
         // Reference `a` (Sphere3.hpp:33), hoisted.
@@ -137,6 +130,7 @@ struct Intersector {
         // direction and tests every sphere.  A sphere can only be hit if its centre, projected on that plane, lies
         // within r of the ray.  The projected distances are shrunk by g < 1 so that everything the reference's own
         // rounding could still accept (E) and this filter's evaluation error (dp) stay inside r.
+        // LDS-resident scenes also scale them by S (a power of two: exact; FilterBounds::scale).
         const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
         const float h2 = fmaf(dx, dx, dz * dz);
         const float inv_h = __builtin_amdgcn_rsqf(h2);
@@ -147,8 +141,11 @@ struct Intersector {
             const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
             const float M = o_len + fb.c_max;
             const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
-            const float dp = 0x1p-19f * M;
-            const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
+            // this filter's own error in a projected coordinate: three FMA roundings on the vector ALUs; on the matrix
+            // pipe the split products' omitted terms (< 2^-15 c_max per coordinate, rtk_device.hpp) plus 16 fp32
+            // accumulation steps of unspecified order and rounding (< 2^-18 M): 2^-14 M leaves a factor 2
+            const float dp = (LDS ? 0x1p-14f : 0x1p-19f) * M;
+            const float g = (LDS ? fb.scale : 1.0f) * (fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f));
             f.e1x = g * u1x; f.e1z = g * u1z;
             f.e2x = g * u2x; f.e2y = g * u2y; f.e2z = g * u2z;
             f.ns1 = -fmaf(r.o.z, f.e1z, r.o.x * f.e1x);
@@ -217,11 +214,16 @@ struct Intersector {
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
-        // The LDS-resident scene, word by word through the descriptors (class words: 16 float4 = 32 x (cx, cz)).  A lane
+        // The LDS-resident scene: the projections p1 = C.e1 - o.e1 and p2 = C.e2 - o.e2 of all 32 spheres of a word for
+        // 32 rays at a time are one v_mfma_f32_32x32x16_bf16 each (sphere coordinates and basis components as exact sums
+        // of bf16 parts, fp32 accumulate; SceneDev, tile_term).  A lane then holds, for one ray, p1 and p2 of 16
+        // consecutive spheres in 16 registers each; per sphere three vector FMAs remain: Q = S^2 r~^2 - p1^2,
+        // X = clamp(Q - p2^2) (exactly 1.0 for a candidate, else 0.0: rtk_scene_prep.hpp), acc = 2 acc + X.  The two
+        // halves of a ray's mask word sit in lanes l and l ^ 32; one v_permlane32_swap brings them together.  A lane
         // keeps every non-zero mask word in its LDS slot and the set of those words in `nz` (bit 31 - w: at most 32
         // words, kMaxLdsSpheres = 1024); then it walks its own candidates in ascending list order.
         auto scan_words = [&]() {
-            const int full = n >> 5, rem = n & 31;
+            const int words = (n + 31) >> 5;
             uint32_t nz = 0;
             auto keep = [&](int w, uint32_t m) {
                 if (m != 0) {
@@ -229,42 +231,113 @@ struct Intersector {
                     nz |= 0x80000000u >> w;
                 }
             };
-            for (int w = 0; w < full; ++w) {
+            // this ray's two 16-term vectors (tile_term): [k] for p1 and for p2
+            uint16_t v1[kTileK], v2[kTileK];
+            {
+                uint16_t pe1x[3], pe1z[3], pn1[3], pe2x[3], pe2y[3], pe2z[3], pn2[3];
+                bf16_split3(f.e1x, pe1x); bf16_split3(f.e1z, pe1z); bf16_split3(f.ns1, pn1);
+                bf16_split3(f.e2x, pe2x); bf16_split3(f.e2y, pe2y); bf16_split3(f.e2z, pe2z); bf16_split3(f.ns2, pn2);
+#pragma unroll
+                for (int k = 0; k < kTileK; ++k) {
+                    int coord, sp, rp;
+                    tile_term(k, coord, sp, rp);
+                    v1[k] = coord == 0 ? pe1x[rp - 1] : coord == 2 ? pe1z[rp - 1] : coord == 1 ? static_cast<uint16_t>(0) : pn1[rp - 1];
+                    v2[k] = coord == 0 ? pe2x[rp - 1] : coord == 2 ? pe2z[rp - 1] : coord == 1 ? pe2y[rp - 1] : pn2[rp - 1];
+                }
+            }
+#ifdef RTK_HOST_EMULATION
+            // CPU build: the same split products summed in fp32, sphere by sphere (the matrix pipe's own summation
+            // order is not modelled: dp covers any)
+            for (int w = 0; w < words; ++w) {
                 const float4 wd = wdesc[w];
-                const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
-                const int kind = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y));
-                const float4* q = filt + off;
+                const bool cls = __float_as_int(wd.y) != 0;
+                const float* table = reinterpret_cast<const float*>(tables + __float_as_int(wd.x));
                 uint32_t m = 0;
-                if (kind != 0) {
-                    const float k2 = fmaf(wd.z, f.e2y, f.ns2), nr2 = -wd.w;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float4 s = q[i];
-                        filter_class(f, k2, nr2, s.x, s.y, m);
-                        filter_class(f, k2, nr2, s.z, s.w, m);
+                for (int rho = 0; rho < 32; ++rho) {
+                    const int i = tile_row_sphere(rho), hf = (rho >> 2) & 1;
+                    const int reg = 2 * ((i & 15) & 7) + ((i & 15) >> 3);          // register 2 m + c holds sphere 16 hf + 8 c + m
+                    const uint16_t* row0 = reinterpret_cast<const uint16_t*>(filt + w * 64 + rho);
+                    const uint16_t* row1 = reinterpret_cast<const uint16_t*>(filt + w * 64 + 32 + rho);
+                    float p1 = 0.0f, p2 = 0.0f;
+                    for (int k = 0; k < kTileK; ++k) {
+                        const float ak = bf16_value(k < 8 ? row0[k] : row1[k - 8]);
+                        p1 = fmaf(ak, bf16_value(v1[k]), p1);
+                        p2 = fmaf(ak, bf16_value(v2[k]), p2);
                     }
-                    RTK_STAT(lane, class_words);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        const float4 s = q[i];
-                        filter_one(f, s.x, s.y, s.z, s.w, m);
-                    }
+                    const float pr2 = cls ? wd.w : table[16 * hf + reg];
+                    const float x = fmaf(-p2, p2, fmaf(-p1, p1, pr2));
+                    if (x > 0.0f && x < 1.0f) RTK_STAT_EACH(clamp_fractions);
+                    if (x > 0.0f) m |= 0x80000000u >> i;
                 }
+                if (cls) RTK_STAT(lane, class_words);
                 RTK_STAT(lane, filter_words);
-                keep(w, m);
+                keep(w, m | __float_as_uint(wd.z));
             }
-            if (rem) {
-                const int off = __builtin_amdgcn_readfirstlane(__float_as_int(wdesc[full].x));      // the last, partial word is always general
-                const float4* q = filt + off;
-                uint32_t m = 0;
-#pragma unroll 4
-                for (int i = 0; i < rem; ++i) {
-                    const float4 s = q[i];
-                    filter_one(f, s.x, s.y, s.z, s.w, m);
+#else
+            // B fragments: lane l supplies B[k = 8 (l >> 5) + j][column l & 31].  For the first 32 rays lanes 0..31 give
+            // their own k 0..7 and lanes 32..63 the k 8..15 of the ray of lane l - 32; for the second 32 rays the other
+            // way round: exactly what v_permlane32_swap(lo, hi) yields.
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            typedef float f32x16 __attribute__((ext_vector_type(16)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            bf16x8 b1[2], b2[2];
+            {
+                u32x4 g1[2], g2[2];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t lo1 = v1[2 * d] | (static_cast<uint32_t>(v1[2 * d + 1]) << 16), hi1 = v1[8 + 2 * d] | (static_cast<uint32_t>(v1[9 + 2 * d]) << 16);
+                    const uint32_t lo2 = v2[2 * d] | (static_cast<uint32_t>(v2[2 * d + 1]) << 16), hi2 = v2[8 + 2 * d] | (static_cast<uint32_t>(v2[9 + 2 * d]) << 16);
+                    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
+                    const u32x2 s2 = __builtin_amdgcn_permlane32_swap(lo2, hi2, false, false);
+                    g1[0][d] = s1[0]; g1[1][d] = s1[1];
+                    g2[0][d] = s2[0]; g2[1][d] = s2[1];
                 }
-                keep(full, m << (32 - rem));
+                __builtin_memcpy(&b1[0], &g1[0], 16); __builtin_memcpy(&b1[1], &g1[1], 16);
+                __builtin_memcpy(&b2[0], &g2[0], 16); __builtin_memcpy(&b2[1], &g2[1], 16);
             }
+            const int hf = lane >> 5;
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < words; ++w) {
+                const float4 wd = wdesc[w];
+                const bool cls = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y)) != 0;
+                const float4 av = filt[w * kWave + lane];
+                bf16x8 a;
+                __builtin_memcpy(&a, &av, 16);
+                float pr[16];
+                if (cls) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pr[e] = wd.w;
+                } else {
+                    const float4* t = tables + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x)) + 4 * hf;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 tv = t[q];
+                        pr[4 * q] = tv.x; pr[4 * q + 1] = tv.y; pr[4 * q + 2] = tv.z; pr[4 * q + 3] = tv.w;
+                    }
+                }
+                uint32_t half[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1[g], zero, 0, 0, 0);
+                    const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2[g], zero, 0, 0, 0);
+                    float acc_e = 0.0f, acc_o = 0.0f;          // registers 2 m: spheres 16 hf + m; registers 2 m + 1: spheres 16 hf + 8 + m
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const float qe = fmaf(-d1[2 * m], d1[2 * m], pr[2 * m]), qo = fmaf(-d1[2 * m + 1], d1[2 * m + 1], pr[2 * m + 1]);
+                        acc_e = fmaf(acc_e, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[2 * m], d2[2 * m], qe), 0.0f, 1.0f));
+                        acc_o = fmaf(acc_o, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[2 * m + 1], d2[2 * m + 1], qo), 0.0f, 1.0f));
+                    }
+                    half[g] = ((static_cast<uint32_t>(acc_e) << 8) | static_cast<uint32_t>(acc_o)) << (hf ? 0 : 16);
+                }
+                // half[0] belongs to the ray of lane (lane & 31), half[1] to that of lane (lane | 32)
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(half[0], half[1], false, false);
+                if (cls) RTK_STAT(lane, class_words);
+                RTK_STAT(lane, filter_words);
+                keep(w, sw[0] | sw[1] | __float_as_uint(wd.z));
+            }
+#endif
+            const int full = n >> 5, rem = n & 31;
             // lanes whose ray the filter cannot judge test every sphere (rare: one vote per ray, outside the word loop)
             if (wave_any(active && !safe)) {
                 if (!safe) {

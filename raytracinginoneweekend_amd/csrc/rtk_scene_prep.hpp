@@ -17,16 +17,17 @@ namespace rtk {
 
 struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
-    std::vector<float4> wdesc;       // compact layout only (SceneDev::wdesc); empty = every word general at offset 32 w
+    std::vector<float4> wdesc;       // matrix-pipe layout only (SceneDev::wdesc); empty = streamed layout
     int class_words = 0;
-    std::vector<char> filterable;    // per sphere: finite, moderate, not an outlier (the filter / the grid may cull it)
+    std::vector<char> filterable;    // per sphere: the filter may reject it (finite, moderate, not an outlier; matrix-pipe layout: radius within the scale's range)
     FilterBounds fb;
     int n = 0, npad = 0;
 };
 
 // Precomputes, bit-identically to the reference's own fp32 operations, radius*radius (Sphere3.hpp:35) and
 // 1/radius (Vector3.cpp:35-37 via Sphere3.hpp:54); classifies the spheres the filter may reject and bounds them.
-// `compact`: words of 32 spheres that share cy and radius get 8-byte records (SceneDev); without it every word is general.
+// `compact`: the layout of LDS-resident scenes, whose projections run on the matrix pipe (SceneDev); without it the
+// streamed layout of larger scenes.
 inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact = false) {
     const int n = s->n, npad = (n + 31) / 32 * 32;
     out.n = n;
@@ -58,7 +59,36 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         std::sort(order.begin(), order.end(), [&](int x, int y) { return std::fabs(s->radius[x]) < std::fabs(s->radius[y]); });
         if (std::fabs(s->radius[order[0]]) * 2.0f < std::fabs(s->radius[order[1]])) { filterable[order[0]] = 0; order.erase(order.begin()); } else break;
     }
-    FilterBounds fb = {0.0f, 0.0f, 1.0f};
+    // The r^2 term of sphere i as the filter uses it, before scaling: fl(r*r) widened by (1+k).
+    auto widened_r2 = [&](int i) {
+        volatile float rr_v = s->radius[i] * s->radius[i];
+        return static_cast<float>(rr_v) * kFilterScaleSq;
+    };
+    // Scale S = 2^s (matrix-pipe layout).  The filter's last two FMAs form X = S^2 (r~^2 - p1^2 - p2^2) and clamp it to
+    // [0, 1]; a candidate (X > 0) must come out as exactly 1.0, i.e. X >= 1.  With Q = fl(S^2 r~^2 - P1^2) and
+    // X = fl(Q - P2^2), P1 and P2 fp32 numbers: a non-zero Q has |Q| >= S^2 r~^2 2^-48 (either it is at least half of
+    // S^2 r~^2, or P1^2 lies within a factor 2 of S^2 r~^2 and the exact difference is a multiple of their common
+    // granule, at least 2^-47 of the larger), and by the same argument a non-zero X has |X| >= |Q| 2^-49.  So X > 0
+    // implies X >= S^2 r~^2 2^-97, and 2^(2s) >= 2^98 / r~^2_min makes that at least 2.  Scaling by a power of two is
+    // exact; a square that overflows gives X = -inf -> 0, correct for a sphere that far outside its radius; S^2 r~^2
+    // itself must stay finite.  s is set from the smallest filterable radius and capped at 60; a sphere whose radius
+    // falls outside what s allows is a candidate for every ray instead (none in any scene of BASELINE.json).
+    int sexp = 0;
+    if (compact && !order.empty()) {
+        float r2_min = inf;
+        for (int i : order) r2_min = std::fmin(r2_min, widened_r2(i));
+        sexp = (98 - std::ilogb(r2_min) + 1) / 2;            // 2 sexp >= 98 - floor(log2 r2_min)
+        sexp = std::max(0, std::min(60, sexp));
+        const float lo = std::ldexp(1.0f, 98 - 2 * sexp), hi = std::ldexp(1.0f, 126 - 2 * sexp);
+        std::vector<int> kept;
+        for (int i : order) {
+            const float r2 = widened_r2(i);
+            if (r2 >= lo && r2 < hi) kept.push_back(i); else filterable[i] = 0;
+        }
+        order.swap(kept);
+    }
+    const float S2 = std::ldexp(1.0f, 2 * sexp);
+    FilterBounds fb = {0.0f, 0.0f, 1.0f, std::ldexp(1.0f, sexp)};
     if (!order.empty()) {
         fb.r_min = inf;
         for (int i : order) {
@@ -92,28 +122,65 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
     out.wdesc.clear();
     out.class_words = 0;
     if (compact) {
-        // One descriptor per word.  Class word: 32 filterable spheres with bit-identical cy and widened r^2.
+        // Matrix-pipe layout (SceneDev): per word a 32 x 16 bf16 tile as 64 lane fragments, a descriptor, and for
+        // general words the table of r^2 terms in the order the lanes hold their results.
         auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };
-        std::vector<float4> packed;
-        packed.reserve(npad);
-        for (int w = 0; w * 32 < npad; ++w) {
+        const int words = npad / 32;
+        std::vector<float4> tiles(static_cast<size_t>(words) * 64), tables;
+        auto pr2_of = [&](int i) { return (i < n && filterable[i]) ? widened_r2(i) * S2 : -inf; };
+        for (int w = 0; w < words; ++w) {
             const int base = w * 32;
             bool cls = base + 32 <= n;
-            for (int i = base; cls && i < base + 32; ++i)
-                cls = filterable[i] && same_bits(filt[i].y, filt[base].y) && same_bits(filt[i].w, filt[base].w);
-            const int32_t off = static_cast<int32_t>(packed.size()), kind = cls ? 1 : 0;
-            float off_f, kind_f;
+            for (int i = base; cls && i < base + 32; ++i) cls = filterable[i] && same_bits(pr2_of(i), pr2_of(base));
+            uint32_t always = 0;
+            for (int i = base; i < base + 32 && i < n; ++i)
+                if (!filterable[i]) always |= 0x80000000u >> (i - base);
+            // the tile: row rho = sphere tile_row_sphere(rho); pads and always-candidates are zero rows
+            uint16_t row[32][kTileK];
+            for (int rho = 0; rho < 32; ++rho) {
+                const int i = base + tile_row_sphere(rho);
+                const bool live = i < n && filterable[i];
+                uint16_t parts[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {bf16_rne(1.0f), 0, 0}};
+                if (live) {
+                    bf16_split3(s->cx[i], parts[0]);
+                    bf16_split3(s->cy[i], parts[1]);
+                    bf16_split3(s->cz[i], parts[2]);
+                }
+                for (int k = 0; k < kTileK; ++k) {
+                    int coord, sp, rp;
+                    tile_term(k, coord, sp, rp);
+                    row[rho][k] = live ? parts[coord][coord == 3 ? 0 : sp - 1] : 0;
+                }
+            }
+            for (int l = 0; l < 64; ++l) {
+                uint16_t frag[8];
+                for (int j = 0; j < 8; ++j) frag[j] = row[l & 31][8 * (l >> 5) + j];
+                std::memcpy(&tiles[static_cast<size_t>(w) * 64 + l], frag, 16);
+            }
+            int32_t off = 0;
+            const int32_t kind = cls ? 1 : 0;
+            if (!cls) {
+                off = static_cast<int32_t>(tiles.size() + tables.size());
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int q = 0; q < 4; ++q) {          // registers 4 q .. 4 q + 3 of a lane in half hf: register 2 m + c is sphere 16 hf + 8 c + m
+                        float v[4];
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = 4 * q + e;
+                            v[e] = pr2_of(base + 16 * hf + 8 * (reg & 1) + (reg >> 1));
+                        }
+                        tables.push_back(make_float4(v[0], v[1], v[2], v[3]));
+                    }
+            } else {
+                ++out.class_words;
+            }
+            float off_f, kind_f, always_f;
             std::memcpy(&off_f, &off, 4);
             std::memcpy(&kind_f, &kind, 4);
-            out.wdesc.push_back(make_float4(off_f, kind_f, cls ? filt[base].y : 0.0f, cls ? filt[base].w : 0.0f));
-            if (cls) {
-                for (int i = base; i < base + 32; i += 2) packed.push_back(make_float4(filt[i].x, filt[i].z, filt[i + 1].x, filt[i + 1].z));
-                ++out.class_words;
-            } else {
-                for (int i = base; i < base + 32; ++i) packed.push_back(filt[i]);
-            }
+            std::memcpy(&always_f, &always, 4);
+            out.wdesc.push_back(make_float4(off_f, kind_f, always_f, cls ? pr2_of(base) : 0.0f));
         }
-        filt.swap(packed);
+        filt = tiles;
+        filt.insert(filt.end(), tables.begin(), tables.end());
     }
 }
 

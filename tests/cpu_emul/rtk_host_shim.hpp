@@ -93,10 +93,13 @@ struct WaveStats {
     unsigned long long closest_hit_calls, filter_words, compact_iters, early_flushes, flush_iters;
     unsigned long long pass_refill_block, pass_assign_iters, pass_start_block, pass_sky_block, pass_hit_block;
     unsigned long long pass_lambert, pass_metal, pass_glass, pass_unit_flush_block, packet_draws, class_words;
+    unsigned long long clamp_fractions;      // filter tests (every lane) whose clamped value fell strictly inside (0, 1)
 };
 extern thread_local WaveStats wave_stats;
 }
 // counted once per wave (by lane 0 of it)
 #define RTK_STAT(lane, name) do { if ((lane) == 0) ++rtk_shim::wave_stats.name; } while (0)
+// counted for every lane
+#define RTK_STAT_EACH(name) do { ++rtk_shim::wave_stats.name; } while (0)
 // counted once per wave when ANY lane satisfies `pred` (an extra vote that exists only in the emulation build)
 #define RTK_STAT_ANY(lane, name, pred) do { const bool any_ = __ballot(pred) != 0ull; if (any_ && (lane) == 0) ++rtk_shim::wave_stats.name; } while (0)

@@ -13,7 +13,7 @@ _libs = {}
 
 STAT_FIELDS = ("closest_hit_calls", "filter_words", "compact_iters", "early_flushes", "flush_iters", "pass_refill_block",
                "pass_assign_iters", "pass_start_block", "pass_sky_block", "pass_hit_block", "pass_lambert", "pass_metal",
-               "pass_glass", "pass_unit_flush_block", "packet_draws", "class_words")
+               "pass_glass", "pass_unit_flush_block", "packet_draws", "class_words", "clamp_fractions")
 
 
 def lib(lanes=1):
@@ -69,10 +69,10 @@ class Emul:
             pass
 
     def scene_info(self):
-        b = np.zeros(3, np.float32)
+        b = np.zeros(4, np.float32)
         f = np.zeros(self.n, np.uint8)
         self._l.emul_scene_info(self._h, b.ctypes.data, f.ctypes.data)
-        return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2])}, f
+        return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2]), "scale": float(b[3])}, f
 
     def class_words(self) -> int:
         """Words of 32 spheres that got 8-byte class records (shared cy and radius); 0 on the staged path."""

@@ -12,6 +12,7 @@ import pytest
 
 from conftest import bits, load_golden
 import raytracinginoneweekend_amd as rt
+import emul
 from emul import Emul
 from oracle import pyoracle as po
 from test_oracle_golden import ties_scene
@@ -246,12 +247,17 @@ def test_class_words_parity_and_conservativeness(groups, n, want_words):
     check(s, rays)
 
 
-def test_mixed_sign_zero_y_is_not_one_class():
-    """cy = -0.0 and +0.0 differ bitwise: a word mixing them stays general (harmless either way; pinned so it is a decision)."""
+def test_a_class_word_needs_one_radius_only():
+    """Class words share the r^2 term; the spheres' heights travel in the word's tile, so they may differ."""
     rng = np.random.default_rng(3)
     s = _class_scene(rng, 32, [(0.0, 0.25)])
     s["cy"][5] = np.float32(-0.0)
+    s["cy"][9] = np.float32(0.7)
+    assert Emul(s).class_words() == 1
+    s["radius"][11] = np.float32(0.26)
     assert Emul(s).class_words() == 0
+    rays = np.concatenate([rng.uniform(-12, 12, (2000, 3)), rng.normal(size=(2000, 3))], 1).astype(np.float32)
+    check(s, rays)
 
 
 @pytest.mark.parametrize("tilt", [0.0, 1e-12, 1e-7, 1e-6, 3e-6, 1e-4, 1e-2])
@@ -281,3 +287,38 @@ def test_translated_class_scene_far_from_the_origin():
     o = rng.uniform(-12, 12, (m, 3)) + np.array([3000.0, -200.0, 1500.0])
     rays = np.concatenate([np.concatenate([o, rng.normal(size=(m, 3))], 1).astype(np.float32), tangent_rays(rng, s, 1500, 0.5, 3000, 1e-5)])
     check(s, rays)
+
+
+def test_tile_layout_helpers():
+    """The word tiles of the matrix-pipe filter: the row -> sphere map is a permutation that hands each lane half 16
+    consecutive spheres, and a coordinate's three bf16 parts add up to it exactly."""
+    import ctypes as C
+    lib = emul.lib(1)
+    rows = [lib.emul_tile_row_sphere(r) for r in range(32)]
+    assert sorted(rows) == list(range(32))
+    for rho, sphere in enumerate(rows):
+        hf = (rho >> 2) & 1
+        assert sphere // 16 == hf                                   # rows 4..7, 12..15, ... belong to lanes 32..63
+    # register reg of a lane in half hf is row (reg & 3) + 8 (reg >> 2) + 4 hf: even registers spheres 16 hf + m, odd ones 16 hf + 8 + m
+    for hf in range(2):
+        for reg in range(16):
+            assert rows[(reg & 3) + 8 * (reg >> 2) + 4 * hf] == 16 * hf + 8 * (reg & 1) + (reg >> 1)
+    lib.emul_bf16_split3_sum.restype = C.c_float
+    lib.emul_bf16_split3_sum.argtypes = [C.c_float]
+    rng = np.random.default_rng(11)
+    for v in np.concatenate([rng.normal(size=2000) * 10.0 ** rng.uniform(-6, 18, 2000), [0.0, -0.0, 1.0, -1000.0, 0.2, 2.0 ** 60]]).astype(np.float32):
+        assert lib.emul_bf16_split3_sum(float(v)) == float(v)
+
+
+def test_every_filter_test_is_exactly_zero_or_one(stock_scene_golden):
+    """The clamped value X = S^2 (r~^2 - p1^2 - p2^2) of a candidate must be exactly 1 (the bits are accumulated in fp32):
+    the scale is chosen so that it cannot fall inside (0, 1) (rtk_scene_prep.hpp)."""
+    e = Emul(stock_scene_golden)
+    z = load_golden("rays_stock.npz")
+    emul.wave_stats(1)
+    for batch in ("primary", "secondary", "grazing", "inside"):
+        e.intersect(z[batch + "_rays"][:4000])
+    st = emul.wave_stats(1)
+    assert st["filter_words"] > 0 and st["clamp_fractions"] == 0
+    info, _ = e.scene_info()
+    assert info["scale"] == 2.0 ** 52                             # r~^2 = 0.04 (1+2^-15)^2: 2 s >= 98 - floor(log2 r~^2) = 103
