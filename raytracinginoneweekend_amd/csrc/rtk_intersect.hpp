@@ -82,6 +82,9 @@ struct Intersector {
 #ifdef RTK_HOST_EMULATION
     uint8_t* dbg_flags = nullptr;   // emulation only: [n] set to 1 for every sphere the filter passes to the exact stage
 #endif
+#ifdef RTK_PROFILE_SECTIONS
+    mutable unsigned long long prof[2] = {0, 0};     // profile builds only (tools/build_variants.py name=-DRTK_PROFILE_SECTIONS=1): shader cycles in the filter, in the exact stage
+#endif
 
     // `list_base`: list entries are 16-bit offsets from it (the list is flushed before an offset could overflow).
     __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int list_base, int& cnt, float& closest, int& best,
@@ -152,6 +155,9 @@ struct Intersector {
             f.ns2 = -fmaf(r.o.z, f.e2z, fmaf(r.o.y, f.e2y, r.o.x * f.e2x));
         }
         RTK_STAT(lane, closest_hit_calls);
+#ifdef RTK_PROFILE_SECTIONS
+        const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
         float closest = t_max;
         int best = -1;
         int cnt = 0;
@@ -297,6 +303,9 @@ struct Intersector {
                 __builtin_memcpy(&b2[0], &g2[0], 16); __builtin_memcpy(&b2[1], &g2[1], 16);
             }
             const int hf = lane >> 5;
+            // For the same reason nothing this wave sent to the vector memory path earlier (the accumulator atomics of a
+            // retired unit, material gathers) may still be queued when the matrix instructions start: vmcnt(0).
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int w = 0; w < words; ++w) {
                 const float4 wd = wdesc[w];
@@ -315,6 +324,11 @@ struct Intersector {
                         const float4 tv = t[q];
                         pr[4 * q] = tv.x; pr[4 * q + 1] = tv.y; pr[4 * q + 2] = tv.z; pr[4 * q + 3] = tv.w;
                     }
+                    // The table must have ARRIVED before the first matrix instruction issues: a global load still in
+                    // flight reads its address registers late, and the compiler is free to make those registers part of
+                    // an MFMA's result tile (seen on the GPU: images differed from run to run; tools/determinism_check.py).
+                    // The empty statement ties the A fragment, which every MFMA below needs, to the loaded values.
+                    asm volatile("" : "+v"(a) : "v"(pr[0]), "v"(pr[4]), "v"(pr[8]), "v"(pr[12]));
                 }
                 uint32_t half[2];
 #pragma unroll
@@ -355,6 +369,10 @@ struct Intersector {
                         for (int b = 0; b < 32; ++b)
                             if (masks[w * kWave + lane] & (0x80000000u >> b)) dbg_flags[w * 32 + b] = 1;
 #endif
+#ifdef RTK_PROFILE_SECTIONS
+            const unsigned long long pt1 = __builtin_readcyclecounter();
+            prof[0] += pt1 - pt0;
+#endif
             // exact stage: every lane pops its own candidates, lowest list index first
             uint32_t m = 0;
             int wb = 0;
@@ -379,6 +397,9 @@ struct Intersector {
                     ++n_exact;
                 }
             }
+#ifdef RTK_PROFILE_SECTIONS
+            prof[1] += __builtin_readcyclecounter() - pt1;
+#endif
         };
         if (!LDS) {
             // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced

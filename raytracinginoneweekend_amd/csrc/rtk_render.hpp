@@ -77,6 +77,9 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     bool queue_empty = false;
     uint32_t wave_passes = 0;
 
+#ifdef RTK_PROFILE_SECTIONS
+    const unsigned long long prof_begin = __builtin_readcyclecounter();
+#endif
     for (;;) {
         // ---- lanes without a live path: next sample of the unit, or retire the unit ----
         bool start = false, need = false;
@@ -211,6 +214,15 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             }
         }
     }
+#ifdef RTK_PROFILE_SECTIONS
+    // profile builds only: where this wave's shader cycles went (wall cycles of the wave: its SIMD interleaves it with the others)
+    if (lane == 0 && blockIdx.x < 3) {
+        const unsigned long long total = __builtin_readcyclecounter() - prof_begin;
+        printf("wave %d.%d: passes %u  cycles/pass: total %.0f  filter %.0f  exact stage %.0f  rest %.0f\n", static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x / kWave),
+               wave_passes, static_cast<double>(total) / wave_passes, static_cast<double>(isect.prof[0]) / wave_passes, static_cast<double>(isect.prof[1]) / wave_passes,
+               static_cast<double>(total - isect.prof[0] - isect.prof[1]) / wave_passes);
+    }
+#endif
     atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
     atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
     atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));

@@ -77,6 +77,19 @@ def _render_sharded_np(ctx, cam, W, H, spp, depth, seed, world, tile_w=8, tile_h
     return deinterleave(np.stack(parts), W, H, world, tile_w, tile_h), rays
 
 
+def test_repeated_full_width_frames_are_bit_identical(gpu_ctx):
+    """Six renders of one 1200x800 frame (enough waves to keep every CU's matrix and memory pipes busy): one image, one ray
+    count.  Guards the hazard found while the filter moved to the matrix pipe — a global load still in flight whose address
+    registers became part of an MFMA result tile made frames differ from run to run (rtk_intersect.hpp)."""
+    W, H, spp = 1200, 800, 40
+    cam = rt.stock_camera(W / H)
+    first, st0 = gpu_ctx.render(cam, W, H, spp, 50, seed=5)
+    for _ in range(5):
+        img, st = gpu_ctx.render(cam, W, H, spp, 50, seed=5)
+        assert st["rays"] == st0["rays"] and st["exact_tests"] == st0["exact_tests"]
+        assert np.array_equal(bits(img), bits(first))
+
+
 @pytest.mark.parametrize("W,H", [(96, 64), (37, 23)])
 def test_one_vs_n_ranks_bit_identical(gpu_ctx, W, H):
     """Tiles interleaved over 1, 2, 3, 8 ranks, and other tile shapes, give the SAME image bits and ray
