@@ -51,7 +51,7 @@ def anchor(path: str, text: str) -> int:
 def build_code_object(tmp: str) -> str:
     from raytracinginoneweekend_amd import build as B
     obj = os.path.join(tmp, "rtk_dev.o")
-    flags = [f for f in B.HIP_FLAGS if f != "-Wall"]
+    flags = [f for f in B.HIP_FLAGS if f != "-Wall"]      # includes -mllvm -amdgpu-mfma-vgpr-form=1
     subprocess.run([B.HIPCC, *flags, "--cuda-device-only", "-gline-tables-only", "-c", "-I", os.path.join(ROOT, "include"),
                     os.path.join(CSRC, "rtk.hip"), "-o", obj], check=True)
     co = os.path.join(tmp, "rtk.co")
@@ -135,7 +135,8 @@ def make_classifier():
     r_end = anchor(R, "atomicAdd(A.stats + 0")
     i_calls = anchor(I, "RTK_STAT(lane, closest_hit_calls)")
     i_words = anchor(I, "auto scan_words = [&]()")
-    i_rem = anchor(I, "// the last, partial word is always general")
+    i_bfrag = anchor(I, "// B fragments: lane l supplies")
+    i_wordloop = next(n for n, ln in enumerate(open(I), 1) if n > i_bfrag and "for (int w = 0; w < words; ++w) {" in ln)
     i_unsafe = anchor(I, "// lanes whose ray the filter cannot judge")
     i_exact = anchor(I, "// exact stage: every lane pops")
     d_lambert = anchor(D, "if (type == 1) {")
@@ -155,19 +156,14 @@ def make_classifier():
                 return "exact: root test (Sphere3.hpp:31-49)"
             lam = [l for f, fl, l in chain if f == "operator()" and fl == "rtk_intersect.hpp"]
             l = max(lam) if lam else 0          # the scan_words frame (the `keep` lambda sits above it in the file)
-            part = l >= i_rem - 1 and l < i_unsafe
-            if "filter_class" in fns:
-                return "filter: class-word tests (32 per word)"
-            if "filter_one" in fns:
-                return "filter: general tests of the partial last word" if part else "filter: general-word tests (32 per word)"
             if lam:
                 if l >= i_exact:
                     return "exact: candidate pop (mask word -> index, loop control)"
                 if l >= i_unsafe:
                     return "filter: unsafe-ray override"
-                if part:
-                    return "filter: general tests of the partial last word"
-                return "filter: word loop (descriptor, per-word constants, mask assembly and store)"
+                if l >= i_wordloop:
+                    return "filter: word loop (A fragment, 4 MFMA, 3 FMA per test, mask assembly and store)"
+                return "filter: per-pass ray vectors (bf16 splits, lane exchange)"
             return "filter: per-ray setup (basis, shrink factor)"
         if line < r_assign:
             return "refill: next sample of the run / flush the run's sums (3 x 64-bit atomic)"
@@ -219,8 +215,8 @@ def emulation_frequencies(width=96, height=64, spp=8):
         emul.lib(64).emul_force_staged(1)
     p = float(s["closest_hit_calls"])
     f = {
-        "filter: class-word tests (32 per word)": s["class_words"] / p,
-        "filter: general-word tests (32 per word)": (s["filter_words"] - s["class_words"]) / p,
+        "filter: word loop (A fragment, 4 MFMA, 3 FMA per test, mask assembly and store)": s["filter_words"] / p,
+        "filter: per-pass ray vectors (bf16 splits, lane exchange)": 1.0,
         "filter: word loop (descriptor, per-word constants, mask assembly and store)": s["filter_words"] / p,
         "filter: general tests of the partial last word": 1.0,
         "filter: per-ray setup (basis, shrink factor)": 1.0,
@@ -264,7 +260,10 @@ def main():
     blocks = collections.OrderedDict()
     for ad, op in ins:
         b = blocks.setdefault(classify(chains[ad]), {"valu": 0, "cyc": 0, "salu": 0, "lds": 0, "vmem": 0, "slow": collections.Counter()})
-        if op.startswith("v_"):
+        if op.startswith("v_mfma"):
+            b["mfma"] = b.get("mfma", 0) + 1
+            b["cyc"] += 32                      # v_mfma_f32_32x32x16_bf16: 32 cycles of the SIMD, not overlapped with its vector instructions (tools/mfma_valu_overlap.hip)
+        elif op.startswith("v_"):
             c = issue_cycles(op)
             b["valu"] += 1
             b["cyc"] += c
@@ -295,6 +294,8 @@ def main():
         fr = freq.get(k, 1.0)
         dyn = b["cyc"] * fr
         slow = " ".join(f"{o}:{n}" for o, n in b["slow"].most_common(6))
+        if b.get("mfma"):
+            slow = f"v_mfma_f32_32x32x16_bf16:{b['mfma']} (32 cycles each) " + slow
         L.append(f"| {k} | {b['valu']} | {b['cyc']} | {b['salu']} | {b['lds']} | {b['vmem']} | {fr:.2f} | {dyn:.0f} | {100 * dyn / total:.1f} % | {slow} |")
     L.append(f"| **sum** | {sum(b['valu'] for b in blocks.values())} | | | | | | **{total:.0f}** | 100 % | |")
     L.append("")
