@@ -26,7 +26,7 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout.  LDS-resident scene: [64 x npad / 32] float4 A fragments of the words' bf16 tiles | [npad / 32] word
+// Dynamic LDS layout.  LDS-resident scene: [filt_lds] float4: A fragments of the words' bf16 tiles, records of a short tail | [npad / 32] word
 // descriptors | [n] exact float4 | [4 waves][npad / 32][64] u32 candidate mask words (the r^2 tables of general words
 // stay in global memory: two words of sixteen on the stock scene, and 40 KiB per workgroup is what four workgroups per
 // CU allow).  Streamed scene: [4][kListCap][64] u16 candidate lists | [4][kStageSpheres] float4 staging chunks, one per wave.
@@ -36,7 +36,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     unsigned char* p = smem;
     if (LDS) {
-        const int nw = sc.npad / 32, nt = nw * 64;
+        const int nw = sc.npad / 32, nt = sc.filt_lds;
         float4* lf = reinterpret_cast<float4*>(p);
         float4* lw = lf + nt;
         float4* le = lw + nw;
@@ -64,13 +64,13 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 }
 
 static size_t lds_bytes(bool lds, const SceneDev& sc) {
-    return lds ? static_cast<size_t>(sc.npad / 32 * 64 + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
+    return lds ? static_cast<size_t>(sc.filt_lds + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
                : kWavesPerBlock * kStageSpheres * sizeof(float4) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
 template <bool LDS, bool GRID = false>
-__global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderArgs A) {
+__global__ __launch_bounds__(kBlockThreads, 4) void render_kernel(const RenderArgs A) {      // room for 4 workgroups per CU: at most 128 VGPRs
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
     if (threadIdx.x < sizeof(CameraDev) / sizeof(float))
@@ -461,6 +461,7 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
     c->scene = {static_cast<const float4*>(c->filt.p), static_cast<const float4*>(c->exact.p), static_cast<const float4*>(c->mat0.p),
                 static_cast<const float4*>(c->mat1.p), n, npad, fb};
     c->scene.filt_len = static_cast<int32_t>(filt.size());
+    c->scene.filt_lds = ps.filt_lds;
     c->class_words = ps.class_words;
     if (compact) {
         if (ps.wdesc.size() != static_cast<size_t>(npad / 32)) return fail(RTK_ERR_HIP, "internal: word descriptor count");

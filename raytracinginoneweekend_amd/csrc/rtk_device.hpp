@@ -129,7 +129,10 @@ struct SceneDev {
     //   radius, which is what every small sphere of the reference's random_scene() is (main.cpp:124) — has the one
     //   value in its descriptor.  Pads and always-candidates: zero rows, r^2 term -inf (the filter never passes them;
     //   always-candidates come back through the descriptor's `always` bits).
-    //   wdesc[w] = (float4 index of the word's r^2 table, kind: 1 = class, always bits, S^2 r^2 (1+k) of a class word).
+    //   A last word of at most kShortTail spheres gets no tile: its spheres follow the tiles as plain records
+    //   (cx, cy, cz, S^2 r^2 (1+k)) and are tested on the vector ALUs (a tile would cost a full word for a few spheres).
+    //   wdesc[w] = (float4 index of the word's r^2 table or of its records, kind: 0 general, 1 class, 2 short tail,
+    //   always bits, S^2 r^2 (1+k) of a class word).
     // Larger scenes (wdesc == nullptr), streamed through LDS chunks and filtered on the vector ALUs:
     //   filt[i] = (cx, cy, cz, r^2 (1+k)), i < npad; pads -inf, always-candidates +inf.
     const float4* filt;   // [filt_len]
@@ -141,7 +144,9 @@ struct SceneDev {
     FilterBounds fb;
     const float4* wdesc = nullptr;   // [npad / 32]
     int32_t filt_len = 0;            // float4 entries of filt
+    int32_t filt_lds = 0;            // matrix-pipe layout: leading entries of filt that the kernels keep in LDS (tiles, short-tail records)
 };
+constexpr int kShortTail = 8;
 
 // ---- the 32 x 16 bf16 tile of a word (A operand) and the matching ray vector (B operand) ----------------------------
 // A coordinate c is split into bf16 parts c = c1 + c2 + c3 (exact: 3 x 8 mantissa bits), a basis component e likewise;
@@ -166,6 +171,9 @@ __host__ __device__ inline int tile_row_sphere(int rho) {
 }
 // float -> bf16 bits, round to nearest even (finite inputs; inf stays inf), and back
 __host__ __device__ inline uint16_t bf16_rne(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v));       // v_cvt_pk_bf16_f32: the same rounding in one instruction
+#endif
     uint32_t u;
     __builtin_memcpy(&u, &v, 4);
     u += 0x7FFFu + ((u >> 16) & 1u);

@@ -229,7 +229,9 @@ struct Intersector {
         // keeps every non-zero mask word in its LDS slot and the set of those words in `nz` (bit 31 - w: at most 32
         // words, kMaxLdsSpheres = 1024); then it walks its own candidates in ascending list order.
         auto scan_words = [&]() {
-            const int words = (n + 31) >> 5;
+            const int full = n >> 5, rem = n & 31;
+            const bool short_tail = rem != 0 && rem <= kShortTail;
+            const int words = short_tail ? full : full + (rem ? 1 : 0);       // words that have a tile
             uint32_t nz = 0;
             auto keep = [&](int w, uint32_t m) {
                 if (m != 0) {
@@ -351,7 +353,20 @@ struct Intersector {
                 keep(w, sw[0] | sw[1] | __float_as_uint(wd.z));
             }
 #endif
-            const int full = n >> 5, rem = n & 31;
+            if (short_tail) {
+                // the few spheres of the last word, on the vector ALUs: the sign of p1^2 + p2^2 - S^2 r~^2, shifted into the word
+                const float4 wd = wdesc[full];
+                const float4* q = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
+                uint32_t m = 0;
+                for (int i = 0; i < rem; ++i) {
+                    const float4 sp = q[i];
+                    const float p1 = fmaf(sp.z, f.e1z, fmaf(sp.x, f.e1x, f.ns1));
+                    const float p2 = fmaf(sp.z, f.e2z, fmaf(sp.y, f.e2y, fmaf(sp.x, f.e2x, f.ns2)));
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(fmaf(p2, p2, fmaf(p1, p1, -sp.w))), 31);
+                }
+                RTK_STAT(lane, tail_tests);
+                keep(full, (m << (32 - rem)) | __float_as_uint(wd.z));
+            }
             // lanes whose ray the filter cannot judge test every sphere (rare: one vote per ray, outside the word loop)
             if (wave_any(active && !safe)) {
                 if (!safe) {

@@ -19,6 +19,7 @@ struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
     std::vector<float4> wdesc;       // matrix-pipe layout only (SceneDev::wdesc); empty = streamed layout
     int class_words = 0;
+    int filt_lds = 0;                // SceneDev::filt_lds
     std::vector<char> filterable;    // per sphere: the filter may reject it (finite, moderate, not an outlier; matrix-pipe layout: radius within the scale's range)
     FilterBounds fb;
     int n = 0, npad = 0;
@@ -125,8 +126,10 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         // Matrix-pipe layout (SceneDev): per word a 32 x 16 bf16 tile as 64 lane fragments, a descriptor, and for
         // general words the table of r^2 terms in the order the lanes hold their results.
         auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };
-        const int words = npad / 32;
-        std::vector<float4> tiles(static_cast<size_t>(words) * 64), tables;
+        const int words = npad / 32, rem = n & 31;
+        const bool short_tail = rem != 0 && rem <= kShortTail;
+        const int tile_words = short_tail ? words - 1 : words;
+        std::vector<float4> tiles(static_cast<size_t>(tile_words) * 64), tables;
         auto pr2_of = [&](int i) { return (i < n && filterable[i]) ? widened_r2(i) * S2 : -inf; };
         for (int w = 0; w < words; ++w) {
             const int base = w * 32;
@@ -135,6 +138,16 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             uint32_t always = 0;
             for (int i = base; i < base + 32 && i < n; ++i)
                 if (!filterable[i]) always |= 0x80000000u >> (i - base);
+            if (w >= tile_words) {           // short tail: plain records right behind the tiles, tested on the vector ALUs
+                const int32_t off = static_cast<int32_t>(tiles.size()), kind = 2;
+                for (int i = base; i < n; ++i) tiles.push_back(filterable[i] ? make_float4(s->cx[i], s->cy[i], s->cz[i], pr2_of(i)) : make_float4(0.f, 0.f, 0.f, -inf));
+                float off_f, kind_f, always_f;
+                std::memcpy(&off_f, &off, 4);
+                std::memcpy(&kind_f, &kind, 4);
+                std::memcpy(&always_f, &always, 4);
+                out.wdesc.push_back(make_float4(off_f, kind_f, always_f, 0.0f));
+                continue;
+            }
             // the tile: row rho = sphere tile_row_sphere(rho); pads and always-candidates are zero rows
             uint16_t row[32][kTileK];
             for (int rho = 0; rho < 32; ++rho) {
@@ -179,6 +192,15 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             std::memcpy(&always_f, &always, 4);
             out.wdesc.push_back(make_float4(off_f, kind_f, always_f, cls ? pr2_of(base) : 0.0f));
         }
+        // offsets of the r^2 tables were taken before the short tail's records were appended to `tiles`
+        if (short_tail)
+            for (int w = 0; w < tile_words; ++w) {
+                int32_t kind, off;
+                std::memcpy(&kind, &out.wdesc[w].y, 4);
+                std::memcpy(&off, &out.wdesc[w].x, 4);
+                if (kind == 0) { off += rem; std::memcpy(&out.wdesc[w].x, &off, 4); }
+            }
+        out.filt_lds = static_cast<int>(tiles.size());
         filt = tiles;
         filt.insert(filt.end(), tables.begin(), tables.end());
     }

@@ -90,6 +90,7 @@ void* emul_create(const rtk_scene* s) {
     prepare_scene(s, e->ps, e->compact);
     e->dev = {e->ps.filt.data(), e->ps.exact.data(), e->ps.m0.data(), e->ps.m1.data(), e->ps.n, e->ps.npad, e->ps.fb};
     e->dev.filt_len = static_cast<int32_t>(e->ps.filt.size());
+    e->dev.filt_lds = e->ps.filt_lds;
     if (e->compact) e->dev.wdesc = e->ps.wdesc.data();
     build_grid(s, e->ps, e->grid);
     e->grid.dev.cell_start = e->grid.cell_start.data();

@@ -93,6 +93,7 @@ struct WaveStats {
     unsigned long long closest_hit_calls, filter_words, compact_iters, early_flushes, flush_iters;
     unsigned long long pass_refill_block, pass_assign_iters, pass_start_block, pass_sky_block, pass_hit_block;
     unsigned long long pass_lambert, pass_metal, pass_glass, pass_unit_flush_block, packet_draws, class_words;
+    unsigned long long tail_tests;           // passes that tested a short last word on the vector ALUs
     unsigned long long clamp_fractions;      // filter tests (every lane) whose clamped value fell strictly inside (0, 1)
 };
 extern thread_local WaveStats wave_stats;

@@ -13,7 +13,7 @@ _libs = {}
 
 STAT_FIELDS = ("closest_hit_calls", "filter_words", "compact_iters", "early_flushes", "flush_iters", "pass_refill_block",
                "pass_assign_iters", "pass_start_block", "pass_sky_block", "pass_hit_block", "pass_lambert", "pass_metal",
-               "pass_glass", "pass_unit_flush_block", "packet_draws", "class_words", "clamp_fractions")
+               "pass_glass", "pass_unit_flush_block", "packet_draws", "class_words", "tail_tests", "clamp_fractions")
 
 
 def lib(lanes=1):

@@ -322,3 +322,17 @@ def test_every_filter_test_is_exactly_zero_or_one(stock_scene_golden):
     assert st["filter_words"] > 0 and st["clamp_fractions"] == 0
     info, _ = e.scene_info()
     assert info["scale"] == 2.0 ** 52                             # r~^2 = 0.04 (1+2^-15)^2: 2 s >= 98 - floor(log2 r~^2) = 103
+
+
+@pytest.mark.parametrize("n", [1, 5, 8, 9, 31, 32, 33, 40, 41, 64, 72, 73, 485])
+def test_last_word_as_short_tail_or_as_tile(n):
+    """A last word of 1..8 spheres is tested on the vector ALUs (no tile), a longer one gets a tile with pads."""
+    rng = np.random.default_rng(500 + n)
+    s = _odd_scene(rng, n)
+    m = 1500
+    rays = np.concatenate([np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32),
+                           tangent_rays(rng, s, 600, 0.5, 200, 1e-5)])
+    emul.wave_stats(1)
+    check(s, rays)
+    st = emul.wave_stats(1)
+    assert (st["tail_tests"] > 0) == (0 < n % 32 <= 8)
