@@ -133,8 +133,16 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         auto pr2_of = [&](int i) { return (i < n && filterable[i]) ? widened_r2(i) * S2 : -inf; };
         for (int w = 0; w < words; ++w) {
             const int base = w * 32;
-            bool cls = base + 32 <= n;
-            for (int i = base; cls && i < base + 32; ++i) cls = filterable[i] && same_bits(pr2_of(i), pr2_of(base));
+            // class word: no pads, and every sphere the filter may reject has the same r^2 term.  An always-candidate in
+            // it is a zero row: its X = S^2 r~^2 > 0 passes, which is what it must do anyway.
+            bool cls = base + 32 <= n, have = false;
+            float cls_pr2 = 0.0f;
+            for (int i = base; cls && i < base + 32; ++i)
+                if (filterable[i]) {
+                    if (!have) { cls_pr2 = pr2_of(i); have = true; }
+                    else cls = same_bits(pr2_of(i), cls_pr2);
+                }
+            cls = cls && have;
             uint32_t always = 0;
             for (int i = base; i < base + 32 && i < n; ++i)
                 if (!filterable[i]) always |= 0x80000000u >> (i - base);
@@ -190,7 +198,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             std::memcpy(&off_f, &off, 4);
             std::memcpy(&kind_f, &kind, 4);
             std::memcpy(&always_f, &always, 4);
-            out.wdesc.push_back(make_float4(off_f, kind_f, always_f, cls ? pr2_of(base) : 0.0f));
+            out.wdesc.push_back(make_float4(off_f, kind_f, always_f, cls ? cls_pr2 : 0.0f));
         }
         // offsets of the r^2 tables were taken before the short tail's records were appended to `tiles`
         if (short_tail)

@@ -29,7 +29,7 @@ class FakeCtx:
         return mode
 
     def scene_layout(self):
-        return {"spheres": self.n, "class_words": 14 if self.n == 484 else 0, "lds_resident": self.n <= 1024, "lds_bytes_per_workgroup": 20000}
+        return {"spheres": self.n, "class_words": 15 if self.n == 484 else 0, "lds_resident": self.n <= 1024, "lds_bytes_per_workgroup": 20000}
 
     def reset_stats(self):
         self.frames = 0

@@ -229,10 +229,11 @@ def _class_scene(rng, n, y_groups, offset=(0.0, 0.0, 0.0), scale=1.0):
     return s
 
 
-def test_stock_scene_has_fourteen_class_words(stock_scene_golden):
-    """random_scene(): ground, 480 small spheres at y = 0.2 with r = 0.2, three big ones -> words 1..14 of 32 are class words."""
+def test_stock_scene_is_fifteen_class_words_and_a_short_tail(stock_scene_golden):
+    """random_scene(): ground (an always-candidate: a zero row in its word), 480 small spheres with r = 0.2, three big ones ->
+    words 0..14 are class words, the last 5 spheres a short tail."""
     e = Emul(stock_scene_golden)
-    assert e.class_words() == 14
+    assert e.class_words() == 15
 
 
 @pytest.mark.parametrize("groups,n,want_words", [([(0.2, 0.2)], 96, 3), ([(0.2, 0.2), None, (1.0, 0.3)], 288, 6), ([None], 64, 0),
