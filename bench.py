@@ -43,7 +43,7 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-KERNEL_TAG = "r02-d (projection filter: the two projections of 32 spheres x 32 rays as one bf16 MFMA each from exact three-part splits, squares/clamp/bit accumulation in 3 fp32 FMAs per test; candidate mask words in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
+KERNEL_TAG = "r02-e (dot-product filter: squared distance minus r^2 of 32 spheres x 32 rays as one f16 MFMA from two-part splits of the centre's monomials and the ray's coefficients, threshold and bit accumulation in 2 fp32 FMAs per test; candidate mask words in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
 
 
 # BASELINE.json configs[0] — the reference's own CPU-runnable case: `400 225 10 50`.  The reference is deterministic
@@ -202,7 +202,7 @@ def main():
         lay = ctx.scene_layout()
         n_class = 32 * lay["class_words"]
         on_matrix_pipe = n_spheres <= 1024
-        filt_valu = 3.0 if on_matrix_pipe else 8.0                                      # vector instructions per ray-sphere filter test
+        filt_valu = 2.0 if on_matrix_pipe else 8.0                                      # vector instructions per ray-sphere filter test
         alg_bytes = args.width * args.height * 3 * (8 + 4) / world                       # per launch: one u64 accumulator + one fp32 sum per channel
         out = {
             "metric": "Mrays/s (whole node), final scene 1200x800 500spp" if headline else
@@ -221,7 +221,8 @@ def main():
                          "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_tag": KERNEL_TAG, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays, "per_rank_kernel_ms": per_rank_ms,
                          "basis": "ALGORITHMIC flops (17 per ray-sphere test x spheres x rays, SURVEY.md §8d) against the fp32 VECTOR peak, not executed ones: the kernel runs a conservative "
-                                  "filter per test (" + ("its two projections on the matrix pipe as split-bf16 products, 4 x v_mfma_f32_32x32x16_bf16 per 32 spheres x 64 rays, then 3 fp32 vector FMAs"
+                                  "filter per test (" + ("one dot product of split-f16 monomials and coefficients on the matrix pipe, 2 x v_mfma_f32_32x32x16_f16 per class word of 32 spheres x 64 rays, then 2 fp32 vector FMAs; "
+                                                         "with most of a test's arithmetic on the matrix pipe the algorithmic fraction of the VECTOR peak may exceed 1"
                                                          if on_matrix_pipe else "8 fp32 vector instructions") +
                                   ") plus ~2 exact reference tests per ray; executed-instruction counts from counters: profiles/*_summary.md",
                          "filter_on_matrix_pipe": on_matrix_pipe,

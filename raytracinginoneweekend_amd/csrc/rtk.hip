@@ -26,10 +26,9 @@ using namespace rtk;
 // Kernels
 // =================================================================================================
 
-// Dynamic LDS layout.  LDS-resident scene: [filt_lds] float4: A fragments of the words' bf16 tiles, records of a short tail | [npad / 32] word
-// descriptors | [n] exact float4 | [4 waves][npad / 32][64] u32 candidate mask words (the r^2 tables of general words
-// stay in global memory: two words of sixteen on the stock scene, and 40 KiB per workgroup is what four workgroups per
-// CU allow).  Streamed scene: [4][kListCap][64] u16 candidate lists | [4][kStageSpheres] float4 staging chunks, one per wave.
+// Dynamic LDS layout.  LDS-resident scene: [filt_lds] float4: A fragments of the words' f16 tiles, records of a short tail | [npad / 32] word
+// descriptors | [n] exact float4 | [4 waves][npad / 32][64] u32 candidate mask words (40 KiB per workgroup is what four
+// workgroups per CU allow: the stock scene needs 39.9).  Streamed scene: [4][kListCap][64] u16 candidate lists | [4][kStageSpheres] float4 staging chunks, one per wave.
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
@@ -44,7 +43,6 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
         for (int i = threadIdx.x; i < nw; i += blockDim.x) lw[i] = sc.wdesc[i];
         for (int i = threadIdx.x; i < sc.n; i += blockDim.x) le[i] = sc.exact[i];
         it.filt = lf;
-        it.tables = sc.filt;
         it.wdesc = lw;
         it.exact = le;
         p += static_cast<size_t>(nt + nw + sc.n) * sizeof(float4);

@@ -108,31 +108,35 @@ __device__ __forceinline__ V3 sample_in_unit_sphere(float u1, float u2, float u3
 // ---------------------------------------------------------------------------------------------
 // Scene as the kernels see it.
 // ---------------------------------------------------------------------------------------------
-// Scene-wide bounds the projection-form filter needs (over the FILTERABLE spheres only; the others
-// carry r^2 = +inf in `filt` and are candidates for every ray).
+// Scene-wide bounds the filter needs (over the FILTERABLE spheres only; the others are candidates for every ray).
 struct FilterBounds {
     float c_max;     // max |C| + |r|
     float r_max2;    // max r^2
     float r_min;     // min |r|
-    float scale;     // S = 2^s: LDS-resident scenes scale the filter's basis by it and the r^2 terms by S^2 (rtk_scene_prep.hpp)
+    // matrix-pipe layout (LDS-resident scenes):
+    float sigma;     // power of two with sigma * c_max <= 1: the tiles hold monomials of the scaled centres C' = sigma C
+    float cls_cy;    // scaled cy' shared by the spheres of every class word
+    float cls_r2;    // their scaled, widened r'^2
+    float acc_eps;   // relative bound of the matrix pipe's evaluation error for this scene's word kinds (kQuadEpsClass / General)
+    int32_t kinds;   // bit 0: the scene has class words, bit 1: general words
 };
 
 struct SceneDev {
     // Filter operands, one block per WORD of 32 consecutive list entries (list order is kept: the exact stage's tie
     // rule depends on it).
-    // Scenes of up to kMaxLdsSpheres spheres (wdesc != nullptr) — the projections run on the matrix pipe:
-    //   filt[64 w + l], w < npad / 32: lane l's 16-byte A fragment of word w for v_mfma_f32_32x32x16_bf16 — row
-    //   l & 31 of the word's 32 x 16 tile, k = 8 (l >> 5) ... + 7, eight bf16: the sphere's split coordinates
-    //   (kTileTerms below).  Row rho holds sphere tile_row_sphere(rho), chosen so that the results a lane receives
-    //   are 16 consecutive spheres.  After the tiles: one table of 2 x 16 r^2 terms (S^2 r^2 (1+k), in the order the
-    //   lanes of either half hold their results) per GENERAL word; a CLASS word — 32 filterable spheres with one
-    //   radius, which is what every small sphere of the reference's random_scene() is (main.cpp:124) — has the one
-    //   value in its descriptor.  Pads and always-candidates: zero rows, r^2 term -inf (the filter never passes them;
-    //   always-candidates come back through the descriptor's `always` bits).
-    //   A last word of at most kShortTail spheres gets no tile: its spheres follow the tiles as plain records
-    //   (cx, cy, cz, S^2 r^2 (1+k)) and are tested on the vector ALUs (a tile would cost a full word for a few spheres).
-    //   wdesc[w] = (float4 index of the word's r^2 table or of its records, kind: 0 general, 1 class, 2 short tail,
-    //   always bits, S^2 r^2 (1+k) of a class word).
+    // Scenes of up to kMaxLdsSpheres spheres (wdesc != nullptr) — the whole filter test is ONE dot product on the
+    // matrix pipe (quad_term below):
+    //   wdesc[w] = (float4 index of the word's tile or records in filt, kind: 0 general, 1 class, 2 short tail,
+    //   always-candidate bits, valid bits).
+    //   A tile is 64 lane fragments per 16 terms: filt[off + 64 h + l] = lane l's 16-byte A fragment of
+    //   v_mfma_f32_32x32x16_f16 — row l & 31, terms 16 h + 8 (l >> 5) ... + 7, eight f16.  Row rho holds sphere
+    //   tile_row_sphere(rho), chosen so that the results a lane receives are 16 consecutive spheres.
+    //   CLASS word (kind 1; one tile fragment set, K = 16): its filterable spheres share cy and radius with the scene's
+    //   class (FilterBounds::cls_cy, cls_r2) — what every small sphere of the reference's random_scene() is
+    //   (main.cpp:124).  GENERAL word (kind 0; two fragment sets, K = 32).  Pads and always-candidates are zero rows;
+    //   the descriptor's valid bits mask what a zero row yields, its always bits are OR-ed in.
+    //   A last word of at most kShortTail spheres gets no tile: its spheres follow as plain records
+    //   (cx, cy, cz, r^2 (1+k)) and are tested on the vector ALUs (a tile would cost a full word for a few spheres).
     // Larger scenes (wdesc == nullptr), streamed through LDS chunks and filtered on the vector ALUs:
     //   filt[i] = (cx, cy, cz, r^2 (1+k)), i < npad; pads -inf, always-candidates +inf.
     const float4* filt;   // [filt_len]
@@ -144,23 +148,34 @@ struct SceneDev {
     FilterBounds fb;
     const float4* wdesc = nullptr;   // [npad / 32]
     int32_t filt_len = 0;            // float4 entries of filt
-    int32_t filt_lds = 0;            // matrix-pipe layout: leading entries of filt that the kernels keep in LDS (tiles, short-tail records)
+    int32_t filt_lds = 0;            // matrix-pipe layout: entries of filt that the kernels keep in LDS (all of it)
 };
 constexpr int kShortTail = 8;
 
-// ---- the 32 x 16 bf16 tile of a word (A operand) and the matching ray vector (B operand) ----------------------------
-// A coordinate c is split into bf16 parts c = c1 + c2 + c3 (exact: 3 x 8 mantissa bits), a basis component e likewise;
-// the product c e is summed from the terms listed here (sphere part, ray part).  x and z: (1,1) (1,2) (2,1) (1,3)
-// (3,1); y: (1,1) (1,2) (2,1); the constant -o.e: 1 x (n1, n2, n3).  What is left out — (2,2) and beyond for x and z,
-// (1,3) (3,1) (2,2) and beyond for y — is below 2^-16 (1 + 2^-6) |c| |e| per product: part of the filter's delta.
-constexpr int kTileK = 16;
-// part (1..3) of the sphere's x, z, y coordinate — or the constant one (coordinate 3) — that row element k holds
-__host__ __device__ inline void tile_term(int k, int& coord, int& sphere_part, int& ray_part) {
-    const int sp5[5] = {1, 1, 2, 1, 3}, rp5[5] = {1, 2, 1, 3, 1};
-    if (k < 5) { coord = 0; sphere_part = sp5[k]; ray_part = rp5[k]; }
-    else if (k < 10) { coord = 2; sphere_part = sp5[k - 5]; ray_part = rp5[k - 5]; }
-    else if (k < 13) { coord = 1; sphere_part = sp5[k - 10]; ray_part = rp5[k - 10]; }
-    else { coord = 3; sphere_part = 1; ray_part = k - 12; }
+// ---- the filter test as one dot product (matrix-pipe layout) --------------------------------------------------------
+// With d the unit direction, p = o' - (o'.d) d the part of the scaled origin perpendicular to the ray and
+// q = I - d d^T, the squared distance of a scaled centre C' from the ray's line is
+//     P = sum_ij q_ij C'_i C'_j - 2 p.C' + |p|^2,
+// bilinear in MONOMIALS of the centre (C'x^2, C'y^2, C'z^2, C'x C'y, C'x C'z, C'y C'z, C'x, C'y, C'z, and r'^2 for the
+// threshold) and COEFFICIENTS of the ray.  Each monomial m (|m| <= 1, times 2^14) and each coefficient c (times t 2^13,
+// t a power of two per ray that keeps |c t| < 4) is split into two f16 parts, m = m1 + m2, c = c1 + c2, both to 2^-24
+// relative; the product is summed from the three terms (m1 c1, m1 c2, m2 c1), what is left out is below 2^-23 |m c|.
+// A class word needs the five monomials without y (cy' and r'^2 are folded into the ray's coefficients and constant):
+// 15 terms, K = 16.  A general word: nine monomials x 3 terms, then r'^2 as two parts against the one-part coefficient
+// -t: 29 terms, K = 32.  The ray's constant stays on the vector ALUs (Intersector::closest_hit).
+constexpr int kQuadClassMonomials = 5;     // xx zz xz x z
+constexpr int kQuadGeneralMonomials = 9;   // xx yy zz xy xz yz x y z
+constexpr float kQuadSphereScale = 0x1p14f, kQuadRayScale = 0x1p13f;
+// Bound, relative to the sum T of the absolute values of all terms and the constant, of everything the evaluation does to
+// the true value: 16 (32) fp32 accumulation steps of unspecified order and rounding, 2^-23 T each;
+// left-out part products and part roundings, 2^-22.4 T; the ray's coefficients and constant in fp32, 2^-19 T.
+constexpr float kQuadEpsClass = 0x1p-19f + 0x1p-19f + 0x1p-22f, kQuadEpsGeneral = 0x1p-18f + 0x1p-19f + 0x1p-22f;
+// term k of a tile row: which monomial, which part (0, 1) of the sphere's monomial and of the ray's coefficient;
+// monomial -1: unused term (zero), monomial `n_mono`: r'^2 (general words only)
+__host__ __device__ inline void quad_term(int k, int n_mono, int& mono, int& sphere_part, int& ray_part) {
+    if (k < 3 * n_mono) { mono = k / 3; sphere_part = (k % 3) == 2; ray_part = (k % 3) == 1; }
+    else if (n_mono == kQuadGeneralMonomials && k < 3 * n_mono + 2) { mono = n_mono; sphere_part = k - 3 * n_mono; ray_part = 0; }
+    else { mono = -1; sphere_part = 0; ray_part = 0; }
 }
 // Result register reg (0..15) of a lane in half hf (lane >> 5) is row (reg & 3) + 8 (reg >> 2) + 4 hf of the tile.  The
 // filter accumulates even registers into one bit string and odd ones into another, so row rho holds this sphere of the
@@ -169,28 +184,54 @@ __host__ __device__ inline int tile_row_sphere(int rho) {
     const int hf = (rho >> 2) & 1, r = rho - 4 * hf, c = r & 1, m = 2 * (r >> 3) + ((r >> 1) & 1);
     return 16 * hf + 8 * c + m;
 }
-// float -> bf16 bits, round to nearest even (finite inputs; inf stays inf), and back
-__host__ __device__ inline uint16_t bf16_rne(float v) {
+// float -> IEEE binary16 bits, round to nearest even (overflow -> inf; subnormals kept), and back
+__host__ __device__ inline uint16_t f16_rne(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v));       // v_cvt_pk_bf16_f32: the same rounding in one instruction
-#endif
+    return __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+#else
     uint32_t u;
     __builtin_memcpy(&u, &v, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
+    const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return static_cast<uint16_t>(sign | (a > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (a >= 0x477FF000u) return static_cast<uint16_t>(sign | 0x7C00u);          // rounds to 2^16 or more
+    if (a < 0x33000001u) return static_cast<uint16_t>(sign);                      // at most 2^-25: rounds to zero
+    const int e = static_cast<int>(a >> 23) - 127;
+    uint32_t m = (a & 0x7FFFFFu) | 0x800000u;                                     // 24-bit significand
+    const int shift = e >= -14 ? 13 : 13 + (-14 - e);                             // bits dropped
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+    m >>= shift;
+    if (rest > half || (rest == half && (m & 1u))) ++m;
+    // normal: m in [0x400, 0x800] with the implicit bit; a carry to 0x800 moves into the exponent by itself
+    const uint32_t bits = e >= -14 ? (static_cast<uint32_t>(e + 15 - 1) << 10) + m : m;
+    return static_cast<uint16_t>(sign | bits);
+#endif
 }
-__host__ __device__ inline float bf16_value(uint16_t b) {
-    const uint32_t u = static_cast<uint32_t>(b) << 16;
+__host__ __device__ inline float f16_value(uint16_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<float>(__builtin_bit_cast(_Float16, b));
+#else
+    const uint32_t sign = static_cast<uint32_t>(b & 0x8000u) << 16, e = (b >> 10) & 0x1Fu, m = b & 0x3FFu;
     float v;
+    if (e == 0) {
+        v = static_cast<float>(m) * 0x1p-24f;
+    } else if (e == 31) {
+        const uint32_t u = 0x7F800000u | (m << 13);
+        __builtin_memcpy(&v, &u, 4);
+    } else {
+        const uint32_t u = ((e + 112u) << 23) | (m << 13);
+        __builtin_memcpy(&v, &u, 4);
+    }
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    u |= sign;
     __builtin_memcpy(&v, &u, 4);
     return v;
+#endif
 }
-// v = p[0] + p[1] + p[2] in bf16 parts
-__host__ __device__ inline void bf16_split3(float v, uint16_t p[3]) {
-    p[0] = bf16_rne(v);
-    const float r1 = v - bf16_value(p[0]);
-    p[1] = bf16_rne(r1);
-    p[2] = bf16_rne(r1 - bf16_value(p[1]));
+// v ~ p[0] + p[1] in f16 parts (|v - p[0] - p[1]| <= 2^-24 |v| while the second part is a normal number)
+__host__ __device__ inline void f16_split2(float v, uint16_t p[2]) {
+    p[0] = f16_rne(v);
+    p[1] = f16_rne(v - f16_value(p[0]));
 }
 
 struct CameraDev {

@@ -10,12 +10,12 @@ namespace rtk {
 
 // Closest hit over the whole list == HittableList::hit (HittableList.hpp:30-42).
 //
-// Stage 1 (filter, all spheres, pure VALU): a conservative sign test — is the sphere's centre, projected on the plane
-// perpendicular to the ray, within r of the ray — every lane of the wavefront testing the same sphere (operands
-// broadcast from LDS; scenes too large for LDS stream through a wave-private LDS chunk).  The plane's basis has
-// e1.y == 0, so a test is 7 FMAs + one funnel shift (8 VALU); words of 32 spheres that share cy and radius
-// (SceneDev::wdesc) fold cy into a per-ray constant: 6 FMAs + the shift (7 VALU).  The sign bits are funnel-shifted
-// into one mask word per 32 spheres.
+// Stage 1 (filter, all spheres): a conservative test — is the sphere's centre within r of the ray's line.
+// LDS-resident scenes evaluate it as ONE dot product per test on the matrix pipe: squared distance minus r^2 is
+// bilinear in monomials of the centre (static, the words' tiles) and coefficients of the ray (built per call); per word
+// of 32 spheres and 64 rays one v_mfma_f32_32x32x16_f16 per 32 rays (two for words of mixed radii), and two vector FMAs
+// per test turn the sign into a mask bit.  Larger scenes stream through a wave-private LDS chunk and test on the vector
+// ALUs with a basis of the plane perpendicular to the ray (e1.y == 0): 7 FMAs + one funnel shift per test.
 // Stage 2 (candidates): LDS-resident scenes keep the mask words themselves — a lane stores each non-zero word in its LDS
 // slot and notes the word in a register bitmap (no loop, no vote per word); streamed scenes compact the bits into a
 // per-lane list of 16-bit indices (a full list triggers an early exact pass).  Ascending list index either way.
@@ -69,9 +69,8 @@ struct GridDev {
 
 template <bool LDS>
 struct Intersector {
-    const float4* filt;    // LDS == true: the words' A fragments in LDS; else SceneDev::filt in global memory
+    const float4* filt;    // LDS == true: the words' tiles and the short tail's records in LDS; else SceneDev::filt in global memory
     const float4* wdesc = nullptr;   // LDS (with LDS == true) or null: word descriptors, SceneDev::wdesc
-    const float4* tables = nullptr;  // LDS == true: SceneDev::filt in global memory (the descriptors' offsets of the r^2 tables index it)
     const float4* exact;   // LDS or global (cx, cy, cz, r*r)
     uint16_t* list;        // !LDS: this wave's candidate list in LDS: [kListCap][64]
     uint32_t* masks = nullptr;   // LDS: this wave's candidate mask words in LDS: [npad / 32][64]
@@ -133,22 +132,21 @@ struct Intersector {
         // direction and tests every sphere.  A sphere can only be hit if its centre, projected on that plane, lies
         // within r of the ray.  The projected distances are shrunk by g < 1 so that everything the reference's own
         // rounding could still accept (E) and this filter's evaluation error (dp) stay inside r.
-        // LDS-resident scenes also scale them by S (a power of two: exact; FilterBounds::scale).
+        // (LDS-resident scenes use this form for a short last word only.)
         const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
         const float h2 = fmaf(dx, dx, dz * dz);
         const float inv_h = __builtin_amdgcn_rsqf(h2);
-        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f) && (h2 > 0x1p-40f);
+        const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
+        // the dot-product form scales the ray's coefficients by 2^-2k, 2^k > sigma |o|, k <= 12
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f) && (h2 > 0x1p-40f) &&
+                          (!LDS || fb.sigma * o_len < 0x1p12f);
         const float u1x = dz * inv_h, u1z = -dx * inv_h;                     // unshrunk basis
         const float u2x = -dy * (dx * inv_h), u2y = h2 * inv_h, u2z = -dy * (dz * inv_h);
         {
-            const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
             const float M = o_len + fb.c_max;
             const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
-            // this filter's own error in a projected coordinate: three FMA roundings on the vector ALUs; on the matrix
-            // pipe the split products' omitted terms (< 2^-15 c_max per coordinate, rtk_device.hpp) plus 16 fp32
-            // accumulation steps of unspecified order and rounding (< 2^-18 M): 2^-14 M leaves a factor 2
-            const float dp = (LDS ? 0x1p-14f : 0x1p-19f) * M;
-            const float g = (LDS ? fb.scale : 1.0f) * (fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f));
+            const float dp = 0x1p-19f * M;          // this form's own error in a projected coordinate: three FMA roundings
+            const float g = fb.r_min * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(fb.r_min, fb.r_min, E)) + 2.0f * dp) * (1.0f - 0x1p-16f);
             f.e1x = g * u1x; f.e1z = g * u1z;
             f.e2x = g * u2x; f.e2y = g * u2y; f.e2z = g * u2z;
             f.ns1 = -fmaf(r.o.z, f.e1z, r.o.x * f.e1x);
@@ -220,14 +218,17 @@ struct Intersector {
                 emit(base + full * 32, to_cand(m, 0xFFFFFFFFu << (32 - rem)));
             }
         };
-        // The LDS-resident scene: the projections p1 = C.e1 - o.e1 and p2 = C.e2 - o.e2 of all 32 spheres of a word for
-        // 32 rays at a time are one v_mfma_f32_32x32x16_bf16 each (sphere coordinates and basis components as exact sums
-        // of bf16 parts, fp32 accumulate; SceneDev, tile_term).  A lane then holds, for one ray, p1 and p2 of 16
-        // consecutive spheres in 16 registers each; per sphere three vector FMAs remain: Q = S^2 r~^2 - p1^2,
-        // X = clamp(Q - p2^2) (exactly 1.0 for a candidate, else 0.0: rtk_scene_prep.hpp), acc = 2 acc + X.  The two
-        // halves of a ray's mask word sit in lanes l and l ^ 32; one v_permlane32_swap brings them together.  A lane
-        // keeps every non-zero mask word in its LDS slot and the set of those words in `nz` (bit 31 - w: at most 32
-        // words, kMaxLdsSpheres = 1024); then it walks its own candidates in ascending list order.
+        // The LDS-resident scene.  With C' = sigma C, o' = sigma o, d the unit direction, p = o' - (o'.d) d and
+        // q = I - d d^T, a sphere can only be hit if  q(C', C') - 2 p.C' + |p|^2 - r'^2 <= (what the reference's rounding
+        // adds).  The left side, times a power of two t per ray, is a dot product of the centre's monomials (the word's
+        // tile, rtk_device.hpp quad_term) and the ray's coefficients, each split into two f16 parts: one
+        // v_mfma_f32_32x32x16_f16 yields it for 32 spheres x 32 rays (two chained for general words), in fp32.  A lane then
+        // holds the values D of 16 spheres for one ray; per sphere two vector FMAs remain: X = clamp(-2^48 (D + K)), K the
+        // ray's constant including the margin (exactly 1.0 for a candidate, else 0.0: every D and K is a multiple of
+        // 2^-48), and acc = 2 acc + X.  The two halves of a ray's mask word sit in lanes l and l ^ 32; one
+        // v_permlane32_swap brings them together.  A lane keeps every non-zero mask word in its LDS slot and the set of
+        // those words in `nz` (bit 31 - w: at most 32 words, kMaxLdsSpheres = 1024); then it walks its own candidates in
+        // ascending list order.
         auto scan_words = [&]() {
             const int full = n >> 5, rem = n & 31;
             const bool short_tail = rem != 0 && rem <= kShortTail;
@@ -239,110 +240,173 @@ struct Intersector {
                     nz |= 0x80000000u >> w;
                 }
             };
-            // this ray's two 16-term vectors (tile_term): [k] for p1 and for p2
-            uint16_t v1[kTileK], v2[kTileK];
-            {
-                uint16_t pe1x[3], pe1z[3], pn1[3], pe2x[3], pe2y[3], pe2z[3], pn2[3];
-                bf16_split3(f.e1x, pe1x); bf16_split3(f.e1z, pe1z); bf16_split3(f.ns1, pn1);
-                bf16_split3(f.e2x, pe2x); bf16_split3(f.e2y, pe2y); bf16_split3(f.e2z, pe2z); bf16_split3(f.ns2, pn2);
+            const bool has_class = (fb.kinds & 1) != 0, has_general = (fb.kinds & 2) != 0;       // wave-uniform
+            // ---- the ray's side of the dot product ----
+            // t = 2^-2k with 2^k > |o'| (k >= 0) keeps every coefficient below 4: |q_ij| t <= 1, |2 p| t < 2.
+            const float sg = fb.sigma;
+            const float ox = r.o.x * sg, oy = r.o.y * sg, oz = r.o.z * sg;
+            const float ol = o_len * sg;
+            int ke = __builtin_amdgcn_frexp_expf(ol);
+            ke = ke < 0 ? 0 : (ke > 12 ? 12 : ke);                           // beyond 12 the lane is not `safe`
+            const float tk = __builtin_ldexpf(1.0f, -ke), t = tk * tk;
+            const float sd = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+            const float px = fmaf(-sd, dx, ox), py = fmaf(-sd, dy, oy), pz = fmaf(-sd, dz, oz);
+            const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
+            // q without cancellation: 1 - dx^2 = dy^2 + dz^2 (|d| = 1 to a few ulp: part of the margin)
+            const float qxx = fmaf(dy, dy, dz * dz), qyy = fmaf(dx, dx, dz * dz), qzz = fmaf(dx, dx, dy * dy);
+            const float qxy = -2.0f * dx * dy, qxz = -2.0f * dx * dz, qyz = -2.0f * dy * dz;
+            // Margin, in the same t-scaled units.  T bounds the sum of the absolute values of all terms and the constant
+            // (|C'| <= c' = sigma c_max <= 1; sum |q_ij C'_i C'_j| <= sqrt(2) c'^2; w = |o'| 2^-k < 1), T1 the reference's
+            // own |o - C|^2 + r^2:  what the reference's rounding could still accept is 2^-19 T1, this
+            // evaluation is within acc_eps T + 2^-22 of the true value (rtk_device.hpp kQuadEps*; 2^-22: f16 parts below
+            // the normal range, should the matrix pipe flush them).
+            const float cp = sg * fb.c_max, rp2 = sg * sg * fb.r_max2;
+            const float w = ol * tk;
+            const float T = fmaf(fmaf(1.42f * cp, cp, rp2), t, fmaf(2.0f * cp, tk, w) * w);
+            const float T1 = fmaf(fmaf(tk, cp, w), fmaf(tk, cp, w), rp2 * t);
+            const float marg = 1.25f * fmaf(fb.acc_eps, T, 0x1p-19f * T1) + 0x1p-21f;
+            const float tb = t * kQuadRayScale;
+            // constants: K t 2^27, pushed away from zero so that it is a multiple of 2^-48, then times -2^48
+            auto constant = [&](float k_t) {
+                float ks = k_t * (kQuadSphereScale * kQuadRayScale);
+                ks = fabsf(ks) < 0x1p-24f ? -0x1p-24f : ks;
+                return ks * -0x1p48f;
+            };
+            const float cy = fb.cls_cy;
+            const float kc = constant(fmaf(fmaf(-2.0f * py, cy, fmaf(qyy, cy * cy, pp)) - fb.cls_r2, t, -marg));
+            const float kg = constant(fmaf(pp, t, -marg));
+            // term vectors (quad_term): class xx zz xz x z; general xx yy zz xy xz yz x y z, then r'^2 against -t
+            uint16_t vc[16], vg[32];
+            if (has_class) {
+                const float co[kQuadClassMonomials] = {qxx * tb, qzz * tb, qxz * tb, fmaf(qxy, cy, -2.0f * px) * tb, fmaf(qyz, cy, -2.0f * pz) * tb};
+                uint16_t parts[kQuadClassMonomials][2];
 #pragma unroll
-                for (int k = 0; k < kTileK; ++k) {
-                    int coord, sp, rp;
-                    tile_term(k, coord, sp, rp);
-                    v1[k] = coord == 0 ? pe1x[rp - 1] : coord == 2 ? pe1z[rp - 1] : coord == 1 ? static_cast<uint16_t>(0) : pn1[rp - 1];
-                    v2[k] = coord == 0 ? pe2x[rp - 1] : coord == 2 ? pe2z[rp - 1] : coord == 1 ? pe2y[rp - 1] : pn2[rp - 1];
+                for (int m = 0; m < kQuadClassMonomials; ++m) f16_split2(co[m], parts[m]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    int mono, sp, rp;
+                    quad_term(k, kQuadClassMonomials, mono, sp, rp);
+                    vc[k] = mono < 0 ? static_cast<uint16_t>(0) : parts[mono][rp];
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) vc[k] = 0;
+            }
+            if (has_general) {
+                const float co[kQuadGeneralMonomials + 1] = {qxx * tb, qyy * tb, qzz * tb, qxy * tb, qxz * tb, qyz * tb, -2.0f * px * tb, -2.0f * py * tb, -2.0f * pz * tb, -tb};
+                uint16_t parts[kQuadGeneralMonomials + 1][2];
+#pragma unroll
+                for (int m = 0; m <= kQuadGeneralMonomials; ++m) f16_split2(co[m], parts[m]);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    int mono, sp, rp;
+                    quad_term(k, kQuadGeneralMonomials, mono, sp, rp);
+                    vg[k] = mono < 0 ? static_cast<uint16_t>(0) : parts[mono][rp];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) vg[k] = 0;
             }
 #ifdef RTK_HOST_EMULATION
-            // CPU build: the same split products summed in fp32, sphere by sphere (the matrix pipe's own summation
-            // order is not modelled: dp covers any)
-            for (int w = 0; w < words; ++w) {
-                const float4 wd = wdesc[w];
+            // CPU build: the same part products summed in fp32, sphere by sphere (the matrix pipe's own summation order is
+            // not modelled: the margin covers any)
+            for (int wi = 0; wi < words; ++wi) {
+                const float4 wd = wdesc[wi];
                 const bool cls = __float_as_int(wd.y) != 0;
-                const float* table = reinterpret_cast<const float*>(tables + __float_as_int(wd.x));
+                const float4* tile = filt + __float_as_int(wd.x);
+                const int kk = cls ? 16 : 32;
                 uint32_t m = 0;
                 for (int rho = 0; rho < 32; ++rho) {
-                    const int i = tile_row_sphere(rho), hf = (rho >> 2) & 1;
-                    const int reg = 2 * ((i & 15) & 7) + ((i & 15) >> 3);          // register 2 m + c holds sphere 16 hf + 8 c + m
-                    const uint16_t* row0 = reinterpret_cast<const uint16_t*>(filt + w * 64 + rho);
-                    const uint16_t* row1 = reinterpret_cast<const uint16_t*>(filt + w * 64 + 32 + rho);
-                    float p1 = 0.0f, p2 = 0.0f;
-                    for (int k = 0; k < kTileK; ++k) {
-                        const float ak = bf16_value(k < 8 ? row0[k] : row1[k - 8]);
-                        p1 = fmaf(ak, bf16_value(v1[k]), p1);
-                        p2 = fmaf(ak, bf16_value(v2[k]), p2);
+                    const int i = tile_row_sphere(rho);
+                    float dsum = 0.0f;
+                    double exact_sum = 0.0, abs_sum = 0.0;          // exact in double: at most 32 products of 22 bits
+                    for (int k = 0; k < kk; ++k) {
+                        const uint16_t* frag = reinterpret_cast<const uint16_t*>(tile + 64 * (k >> 4) + 32 * ((k >> 3) & 1) + rho);
+                        const float ak = f16_value(frag[k & 7]), bk = f16_value(cls ? vc[k] : vg[k]);
+                        dsum = fmaf(ak, bk, dsum);
+                        exact_sum += static_cast<double>(ak) * bk;
+                        abs_sum += std::fabs(static_cast<double>(ak) * bk);
                     }
-                    const float pr2 = cls ? wd.w : table[16 * hf + reg];
-                    const float x = fmaf(-p2, p2, fmaf(-p1, p1, pr2));
+                    // with hardware noise switched on: the worst accumulation the margin allows for (kk steps of 2^-23 of
+                    // the absolute sum at noise level 3), pushed towards "no candidate"
+                    if (rtk_shim::ulp_noise > 0 && abs_sum < 1e30)
+                        dsum = static_cast<float>(exact_sum + rtk_shim::ulp_noise / 3.0 * kk * 0x1p-23 * abs_sum) + 0.0f;
+                    const float x = fmaf(dsum, -0x1p48f, cls ? kc : kg);
                     if (x > 0.0f && x < 1.0f) RTK_STAT_EACH(clamp_fractions);
                     if (x > 0.0f) m |= 0x80000000u >> i;
                 }
                 if (cls) RTK_STAT(lane, class_words);
                 RTK_STAT(lane, filter_words);
-                keep(w, m | __float_as_uint(wd.z));
+                keep(wi, (m & __float_as_uint(wd.w)) | __float_as_uint(wd.z));
             }
 #else
             // B fragments: lane l supplies B[k = 8 (l >> 5) + j][column l & 31].  For the first 32 rays lanes 0..31 give
             // their own k 0..7 and lanes 32..63 the k 8..15 of the ray of lane l - 32; for the second 32 rays the other
-            // way round: exactly what v_permlane32_swap(lo, hi) yields.
-            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            // way round: exactly what v_permlane32_swap(lo, hi) yields.  The constants travel the same way.
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
             typedef float f32x16 __attribute__((ext_vector_type(16)));
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            bf16x8 b1[2], b2[2];
-            {
-                u32x4 g1[2], g2[2];
+            auto fragments = [](const uint16_t* v, f16x8 out[2]) {          // 16 terms -> the B operands of the two ray groups
+                u32x4 g0, g1;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const uint32_t lo1 = v1[2 * d] | (static_cast<uint32_t>(v1[2 * d + 1]) << 16), hi1 = v1[8 + 2 * d] | (static_cast<uint32_t>(v1[9 + 2 * d]) << 16);
-                    const uint32_t lo2 = v2[2 * d] | (static_cast<uint32_t>(v2[2 * d + 1]) << 16), hi2 = v2[8 + 2 * d] | (static_cast<uint32_t>(v2[9 + 2 * d]) << 16);
-                    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
-                    const u32x2 s2 = __builtin_amdgcn_permlane32_swap(lo2, hi2, false, false);
-                    g1[0][d] = s1[0]; g1[1][d] = s1[1];
-                    g2[0][d] = s2[0]; g2[1][d] = s2[1];
+                    const uint32_t lo = v[2 * d] | (static_cast<uint32_t>(v[2 * d + 1]) << 16), hi = v[8 + 2 * d] | (static_cast<uint32_t>(v[9 + 2 * d]) << 16);
+                    const u32x2 sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+                    g0[d] = sw[0]; g1[d] = sw[1];
                 }
-                __builtin_memcpy(&b1[0], &g1[0], 16); __builtin_memcpy(&b1[1], &g1[1], 16);
-                __builtin_memcpy(&b2[0], &g2[0], 16); __builtin_memcpy(&b2[1], &g2[1], 16);
+                __builtin_memcpy(&out[0], &g0, 16); __builtin_memcpy(&out[1], &g1, 16);
+            };
+            f16x8 bc[2], bg0[2], bg1[2];
+            fragments(vc, bc);
+            fragments(vg, bg0);
+            fragments(vg + 16, bg1);
+            float kcg[2], kgg[2];
+            {
+                const u32x2 a1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(kc), __float_as_uint(kc), false, false);
+                const u32x2 a2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(kg), __float_as_uint(kg), false, false);
+                kcg[0] = __uint_as_float(a1[0]); kcg[1] = __uint_as_float(a1[1]);
+                kgg[0] = __uint_as_float(a2[0]); kgg[1] = __uint_as_float(a2[1]);
             }
             const int hf = lane >> 5;
-            // For the same reason nothing this wave sent to the vector memory path earlier (the accumulator atomics of a
-            // retired unit, material gathers) may still be queued when the matrix instructions start: vmcnt(0).
+            // Nothing this wave sent to the vector memory path earlier (the accumulator atomics of a retired unit, material
+            // gathers) may still be queued when the matrix instructions start: such an instruction reads its address
+            // registers late, and the compiler is free to make those registers part of an MFMA's result tile (seen on the
+            // GPU: images differed from run to run; tools/determinism_check.py).
             __builtin_amdgcn_s_waitcnt(0x0F70);
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int w = 0; w < words; ++w) {
-                const float4 wd = wdesc[w];
+            const float nbig = -0x1p48f;
+            for (int wi = 0; wi < words; ++wi) {
+                const float4 wd = wdesc[wi];
                 const bool cls = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y)) != 0;
-                const float4 av = filt[w * kWave + lane];
-                bf16x8 a;
-                __builtin_memcpy(&a, &av, 16);
-                float pr[16];
-                if (cls) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) pr[e] = wd.w;
-                } else {
-                    const float4* t = tables + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x)) + 4 * hf;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 tv = t[q];
-                        pr[4 * q] = tv.x; pr[4 * q + 1] = tv.y; pr[4 * q + 2] = tv.z; pr[4 * q + 3] = tv.w;
+                const float4* tile = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
+                f32x16 dd[2];
+                float kk[2];
+                {
+                    const float4 av = tile[lane];
+                    f16x8 a0;
+                    __builtin_memcpy(&a0, &av, 16);
+                    if (cls) {
+                        dd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
+                        dd[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
+                        kk[0] = kcg[0]; kk[1] = kcg[1];
+                    } else {
+                        const float4 av1 = tile[kWave + lane];
+                        f16x8 a1;
+                        __builtin_memcpy(&a1, &av1, 16);
+                        dd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[0], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[0], zero, 0, 0, 0), 0, 0, 0);
+                        dd[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[1], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[1], zero, 0, 0, 0), 0, 0, 0);
+                        kk[0] = kgg[0]; kk[1] = kgg[1];
                     }
-                    // The table must have ARRIVED before the first matrix instruction issues: a global load still in
-                    // flight reads its address registers late, and the compiler is free to make those registers part of
-                    // an MFMA's result tile (seen on the GPU: images differed from run to run; tools/determinism_check.py).
-                    // The empty statement ties the A fragment, which every MFMA below needs, to the loaded values.
-                    asm volatile("" : "+v"(a) : "v"(pr[0]), "v"(pr[4]), "v"(pr[8]), "v"(pr[12]));
                 }
                 uint32_t half[2];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1[g], zero, 0, 0, 0);
-                    const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2[g], zero, 0, 0, 0);
                     float acc_e = 0.0f, acc_o = 0.0f;          // registers 2 m: spheres 16 hf + m; registers 2 m + 1: spheres 16 hf + 8 + m
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
-                        const float qe = fmaf(-d1[2 * m], d1[2 * m], pr[2 * m]), qo = fmaf(-d1[2 * m + 1], d1[2 * m + 1], pr[2 * m + 1]);
-                        acc_e = fmaf(acc_e, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[2 * m], d2[2 * m], qe), 0.0f, 1.0f));
-                        acc_o = fmaf(acc_o, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[2 * m + 1], d2[2 * m + 1], qo), 0.0f, 1.0f));
+                        acc_e = fmaf(acc_e, 2.0f, __builtin_amdgcn_fmed3f(fmaf(dd[g][2 * m], nbig, kk[g]), 0.0f, 1.0f));
+                        acc_o = fmaf(acc_o, 2.0f, __builtin_amdgcn_fmed3f(fmaf(dd[g][2 * m + 1], nbig, kk[g]), 0.0f, 1.0f));
                     }
                     half[g] = ((static_cast<uint32_t>(acc_e) << 8) | static_cast<uint32_t>(acc_o)) << (hf ? 0 : 16);
                 }
@@ -350,11 +414,11 @@ struct Intersector {
                 const u32x2 sw = __builtin_amdgcn_permlane32_swap(half[0], half[1], false, false);
                 if (cls) RTK_STAT(lane, class_words);
                 RTK_STAT(lane, filter_words);
-                keep(w, sw[0] | sw[1] | __float_as_uint(wd.z));
+                keep(wi, ((sw[0] | sw[1]) & __float_as_uint(wd.w)) | __float_as_uint(wd.z));
             }
 #endif
             if (short_tail) {
-                // the few spheres of the last word, on the vector ALUs: the sign of p1^2 + p2^2 - S^2 r~^2, shifted into the word
+                // the few spheres of the last word, on the vector ALUs: the sign of p1^2 + p2^2 - r~^2, shifted into the word
                 const float4 wd = wdesc[full];
                 const float4* q = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
                 uint32_t m = 0;

@@ -20,7 +20,7 @@ struct PreparedScene {
     std::vector<float4> wdesc;       // matrix-pipe layout only (SceneDev::wdesc); empty = streamed layout
     int class_words = 0;
     int filt_lds = 0;                // SceneDev::filt_lds
-    std::vector<char> filterable;    // per sphere: the filter may reject it (finite, moderate, not an outlier; matrix-pipe layout: radius within the scale's range)
+    std::vector<char> filterable;    // per sphere: the filter may reject it (finite, moderate, not an outlier)
     FilterBounds fb;
     int n = 0, npad = 0;
 };
@@ -65,31 +65,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         volatile float rr_v = s->radius[i] * s->radius[i];
         return static_cast<float>(rr_v) * kFilterScaleSq;
     };
-    // Scale S = 2^s (matrix-pipe layout).  The filter's last two FMAs form X = S^2 (r~^2 - p1^2 - p2^2) and clamp it to
-    // [0, 1]; a candidate (X > 0) must come out as exactly 1.0, i.e. X >= 1.  With Q = fl(S^2 r~^2 - P1^2) and
-    // X = fl(Q - P2^2), P1 and P2 fp32 numbers: a non-zero Q has |Q| >= S^2 r~^2 2^-48 (either it is at least half of
-    // S^2 r~^2, or P1^2 lies within a factor 2 of S^2 r~^2 and the exact difference is a multiple of their common
-    // granule, at least 2^-47 of the larger), and by the same argument a non-zero X has |X| >= |Q| 2^-49.  So X > 0
-    // implies X >= S^2 r~^2 2^-97, and 2^(2s) >= 2^98 / r~^2_min makes that at least 2.  Scaling by a power of two is
-    // exact; a square that overflows gives X = -inf -> 0, correct for a sphere that far outside its radius; S^2 r~^2
-    // itself must stay finite.  s is set from the smallest filterable radius and capped at 60; a sphere whose radius
-    // falls outside what s allows is a candidate for every ray instead (none in any scene of BASELINE.json).
-    int sexp = 0;
-    if (compact && !order.empty()) {
-        float r2_min = inf;
-        for (int i : order) r2_min = std::fmin(r2_min, widened_r2(i));
-        sexp = (98 - std::ilogb(r2_min) + 1) / 2;            // 2 sexp >= 98 - floor(log2 r2_min)
-        sexp = std::max(0, std::min(60, sexp));
-        const float lo = std::ldexp(1.0f, 98 - 2 * sexp), hi = std::ldexp(1.0f, 126 - 2 * sexp);
-        std::vector<int> kept;
-        for (int i : order) {
-            const float r2 = widened_r2(i);
-            if (r2 >= lo && r2 < hi) kept.push_back(i); else filterable[i] = 0;
-        }
-        order.swap(kept);
-    }
-    const float S2 = std::ldexp(1.0f, 2 * sexp);
-    FilterBounds fb = {0.0f, 0.0f, 1.0f, std::ldexp(1.0f, sexp)};
+    FilterBounds fb = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, kQuadEpsClass, 0};
     if (!order.empty()) {
         fb.r_min = inf;
         for (int i : order) {
@@ -123,94 +99,110 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
     out.wdesc.clear();
     out.class_words = 0;
     if (compact) {
-        // Matrix-pipe layout (SceneDev): per word a 32 x 16 bf16 tile as 64 lane fragments, a descriptor, and for
-        // general words the table of r^2 terms in the order the lanes hold their results.
+        // Matrix-pipe layout (SceneDev): per word a tile of f16 monomial parts as lane fragments and a descriptor.
         auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };
         const int words = npad / 32, rem = n & 31;
         const bool short_tail = rem != 0 && rem <= kShortTail;
         const int tile_words = short_tail ? words - 1 : words;
-        std::vector<float4> tiles(static_cast<size_t>(tile_words) * 64), tables;
-        auto pr2_of = [&](int i) { return (i < n && filterable[i]) ? widened_r2(i) * S2 : -inf; };
-        for (int w = 0; w < words; ++w) {
+        // sigma: the power of two that brings every filterable centre (plus radius) into the unit ball
+        int ec = 0;
+        if (!order.empty()) ec = std::max(-60, std::min(60, static_cast<int>(std::ceil(std::log2(static_cast<double>(fb.c_max))))));
+        while (std::ldexp(static_cast<double>(fb.c_max), -ec) > 1.0) ++ec;
+        const double sigma = std::ldexp(1.0, -ec);
+        fb.sigma = static_cast<float>(sigma);
+        // The scene's class: the (cy, r~^2) pair shared by the filterable spheres of the most words.  A word qualifies
+        // when it has no pads and all its filterable spheres (at least one) agree in both, bit for bit.
+        struct Key { float cy, r2; int count; };
+        std::vector<Key> keys;
+        std::vector<int> word_key(words, -1);
+        for (int w = 0; w < tile_words; ++w) {
             const int base = w * 32;
-            // class word: no pads, and every sphere the filter may reject has the same r^2 term.  An always-candidate in
-            // it is a zero row: its X = S^2 r~^2 > 0 passes, which is what it must do anyway.
-            bool cls = base + 32 <= n, have = false;
-            float cls_pr2 = 0.0f;
-            for (int i = base; cls && i < base + 32; ++i)
+            if (base + 32 > n) continue;
+            bool ok = true, have = false;
+            float cy = 0.0f, r2 = 0.0f;
+            for (int i = base; ok && i < base + 32; ++i)
                 if (filterable[i]) {
-                    if (!have) { cls_pr2 = pr2_of(i); have = true; }
-                    else cls = same_bits(pr2_of(i), cls_pr2);
+                    if (!have) { cy = s->cy[i]; r2 = widened_r2(i); have = true; }
+                    else ok = same_bits(s->cy[i], cy) && same_bits(widened_r2(i), r2);
                 }
-            cls = cls && have;
-            uint32_t always = 0;
-            for (int i = base; i < base + 32 && i < n; ++i)
-                if (!filterable[i]) always |= 0x80000000u >> (i - base);
-            if (w >= tile_words) {           // short tail: plain records right behind the tiles, tested on the vector ALUs
-                const int32_t off = static_cast<int32_t>(tiles.size()), kind = 2;
-                for (int i = base; i < n; ++i) tiles.push_back(filterable[i] ? make_float4(s->cx[i], s->cy[i], s->cz[i], pr2_of(i)) : make_float4(0.f, 0.f, 0.f, -inf));
-                float off_f, kind_f, always_f;
-                std::memcpy(&off_f, &off, 4);
-                std::memcpy(&kind_f, &kind, 4);
-                std::memcpy(&always_f, &always, 4);
-                out.wdesc.push_back(make_float4(off_f, kind_f, always_f, 0.0f));
-                continue;
-            }
-            // the tile: row rho = sphere tile_row_sphere(rho); pads and always-candidates are zero rows
-            uint16_t row[32][kTileK];
-            for (int rho = 0; rho < 32; ++rho) {
-                const int i = base + tile_row_sphere(rho);
-                const bool live = i < n && filterable[i];
-                uint16_t parts[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {bf16_rne(1.0f), 0, 0}};
-                if (live) {
-                    bf16_split3(s->cx[i], parts[0]);
-                    bf16_split3(s->cy[i], parts[1]);
-                    bf16_split3(s->cz[i], parts[2]);
-                }
-                for (int k = 0; k < kTileK; ++k) {
-                    int coord, sp, rp;
-                    tile_term(k, coord, sp, rp);
-                    row[rho][k] = live ? parts[coord][coord == 3 ? 0 : sp - 1] : 0;
-                }
-            }
+            if (!ok || !have) continue;
+            int k = -1;
+            for (size_t q = 0; q < keys.size(); ++q) if (same_bits(keys[q].cy, cy) && same_bits(keys[q].r2, r2)) k = static_cast<int>(q);
+            if (k < 0) { keys.push_back({cy, r2, 0}); k = static_cast<int>(keys.size()) - 1; }
+            ++keys[k].count;
+            word_key[w] = k;
+        }
+        int cls_key = -1;
+        for (size_t q = 0; q < keys.size(); ++q) if (cls_key < 0 || keys[q].count > keys[cls_key].count) cls_key = static_cast<int>(q);
+        if (cls_key >= 0) {
+            fb.cls_cy = static_cast<float>(sigma * keys[cls_key].cy);
+            fb.cls_r2 = static_cast<float>(sigma * sigma * keys[cls_key].r2);
+        }
+        std::vector<float4> tiles;
+        // one 16-term fragment set: rows[rho][k], k < 16 -> 64 lane fragments (lane l: row l & 31, terms 8 (l >> 5) ... + 7)
+        auto push_fragments = [&](const uint16_t (*rows)[32], int k0) {
             for (int l = 0; l < 64; ++l) {
                 uint16_t frag[8];
-                for (int j = 0; j < 8; ++j) frag[j] = row[l & 31][8 * (l >> 5) + j];
-                std::memcpy(&tiles[static_cast<size_t>(w) * 64 + l], frag, 16);
+                for (int j = 0; j < 8; ++j) frag[j] = rows[l & 31][k0 + 8 * (l >> 5) + j];
+                float4 v;
+                std::memcpy(&v, frag, 16);
+                tiles.push_back(v);
             }
-            int32_t off = 0;
-            const int32_t kind = cls ? 1 : 0;
-            if (!cls) {
-                off = static_cast<int32_t>(tiles.size() + tables.size());
-                for (int hf = 0; hf < 2; ++hf)
-                    for (int q = 0; q < 4; ++q) {          // registers 4 q .. 4 q + 3 of a lane in half hf: register 2 m + c is sphere 16 hf + 8 c + m
-                        float v[4];
-                        for (int e = 0; e < 4; ++e) {
-                            const int reg = 4 * q + e;
-                            v[e] = pr2_of(base + 16 * hf + 8 * (reg & 1) + (reg >> 1));
-                        }
-                        tables.push_back(make_float4(v[0], v[1], v[2], v[3]));
-                    }
+        };
+        bool any_general = false;
+        for (int w = 0; w < words; ++w) {
+            const int base = w * 32;
+            uint32_t always = 0, valid = 0;
+            for (int i = base; i < base + 32 && i < n; ++i) {
+                valid |= 0x80000000u >> (i - base);
+                if (!filterable[i]) always |= 0x80000000u >> (i - base);
+            }
+            const int32_t off = static_cast<int32_t>(tiles.size());
+            int32_t kind;
+            if (w >= tile_words) {           // short tail: plain records behind the tiles, tested on the vector ALUs
+                kind = 2;
+                for (int i = base; i < n; ++i) tiles.push_back(filterable[i] ? make_float4(s->cx[i], s->cy[i], s->cz[i], widened_r2(i)) : make_float4(0.f, 0.f, 0.f, -inf));
             } else {
-                ++out.class_words;
+                const bool cls = word_key[w] >= 0 && word_key[w] == cls_key;
+                kind = cls ? 1 : 0;
+                const int n_mono = cls ? kQuadClassMonomials : kQuadGeneralMonomials, kk = cls ? 16 : 32;
+                // the tile: row rho = sphere tile_row_sphere(rho); pads and always-candidates are zero rows
+                uint16_t rows[32][32];
+                for (int rho = 0; rho < 32; ++rho) {
+                    const int i = base + tile_row_sphere(rho);
+                    const bool live = i < n && filterable[i];
+                    uint16_t parts[kQuadGeneralMonomials + 1][2] = {};
+                    if (live) {
+                        const double x = sigma * s->cx[i], y = sigma * s->cy[i], z = sigma * s->cz[i];
+                        const double mono_c[kQuadClassMonomials] = {x * x, z * z, x * z, x, z};
+                        const double mono_g[kQuadGeneralMonomials + 1] = {x * x, y * y, z * z, x * y, x * z, y * z, x, y, z, sigma * sigma * widened_r2(i)};
+                        for (int m = 0; m < (cls ? n_mono : n_mono + 1); ++m) {
+                            const double v = (cls ? mono_c[m] : mono_g[m]) * kQuadSphereScale;
+                            parts[m][0] = f16_rne(static_cast<float>(v));
+                            parts[m][1] = f16_rne(static_cast<float>(v - static_cast<double>(f16_value(parts[m][0]))));
+                        }
+                    }
+                    for (int k = 0; k < 32; ++k) {
+                        int mono, sp, rp;
+                        quad_term(k, n_mono, mono, sp, rp);
+                        rows[rho][k] = (k < kk && live && mono >= 0) ? parts[mono][sp] : static_cast<uint16_t>(0);
+                    }
+                }
+                push_fragments(rows, 0);
+                if (!cls) { push_fragments(rows, 16); any_general = true; } else ++out.class_words;
             }
-            float off_f, kind_f, always_f;
+            float off_f, kind_f, always_f, valid_f;
             std::memcpy(&off_f, &off, 4);
             std::memcpy(&kind_f, &kind, 4);
             std::memcpy(&always_f, &always, 4);
-            out.wdesc.push_back(make_float4(off_f, kind_f, always_f, cls ? cls_pr2 : 0.0f));
+            std::memcpy(&valid_f, &valid, 4);
+            out.wdesc.push_back(make_float4(off_f, kind_f, always_f, valid_f));
         }
-        // offsets of the r^2 tables were taken before the short tail's records were appended to `tiles`
-        if (short_tail)
-            for (int w = 0; w < tile_words; ++w) {
-                int32_t kind, off;
-                std::memcpy(&kind, &out.wdesc[w].y, 4);
-                std::memcpy(&off, &out.wdesc[w].x, 4);
-                if (kind == 0) { off += rem; std::memcpy(&out.wdesc[w].x, &off, 4); }
-            }
+        fb.kinds = (out.class_words ? 1 : 0) | (any_general ? 2 : 0);
+        fb.acc_eps = any_general ? kQuadEpsGeneral : kQuadEpsClass;
+        out.fb = fb;
         out.filt_lds = static_cast<int>(tiles.size());
         filt = tiles;
-        filt.insert(filt.end(), tables.begin(), tables.end());
     }
 }
 

@@ -69,7 +69,6 @@ static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, 
     it.filt = e.ps.filt.data();
     if (LDS) {
         it.wdesc = e.ps.wdesc.data();
-        it.tables = e.ps.filt.data();
         it.masks = masks;
     }
     it.exact = e.ps.exact.data();
@@ -116,17 +115,16 @@ int emul_class_words(void* h) { return static_cast<Emul*>(h)->ps.class_words; }
 void emul_set_ulp_noise(int k) { rtk_shim::ulp_noise = k; }
 // layout helpers of the matrix-pipe filter (rtk_device.hpp)
 int emul_tile_row_sphere(int rho) { return tile_row_sphere(rho); }
-float emul_bf16_split3_sum(float v) {
-    uint16_t p[3];
-    bf16_split3(v, p);
-    return (bf16_value(p[0]) + bf16_value(p[1])) + bf16_value(p[2]);
-}
+uint16_t emul_f16_rne(float v) { return f16_rne(v); }
+float emul_f16_value(uint16_t b) { return f16_value(b); }
+void emul_quad_term(int k, int n_mono, int* out3) { quad_term(k, n_mono, out3[0], out3[1], out3[2]); }
 void emul_force_staged(int on) { g_force_staged = on != 0; }
 
 // filter bounds and per-sphere "filterable" flag as prepare_scene decided them
-void emul_scene_info(void* h, float* bounds4, uint8_t* filterable) {
+void emul_scene_info(void* h, float* bounds8, uint8_t* filterable) {
     const Emul& e = *static_cast<Emul*>(h);
-    bounds4[0] = e.ps.fb.c_max; bounds4[1] = e.ps.fb.r_max2; bounds4[2] = e.ps.fb.r_min; bounds4[3] = e.ps.fb.scale;
+    bounds8[0] = e.ps.fb.c_max; bounds8[1] = e.ps.fb.r_max2; bounds8[2] = e.ps.fb.r_min; bounds8[3] = e.ps.fb.sigma;
+    bounds8[4] = e.ps.fb.cls_cy; bounds8[5] = e.ps.fb.cls_r2; bounds8[6] = e.ps.fb.acc_eps; bounds8[7] = static_cast<float>(e.ps.fb.kinds);
     for (int i = 0; i < e.ps.n; ++i) filterable[i] = e.ps.filterable[i] ? 1 : 0;
 }
 

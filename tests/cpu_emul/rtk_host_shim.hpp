@@ -59,6 +59,8 @@ inline float nudge(float x) {
     float y; std::memcpy(&y, &u, 4);
     return y;
 }
+// v_frexp_exp_i32_f32: 0 for zero, infinities and NaN
+inline int frexp_exp(float x) { int e = 0; if (x == 0.0f || !std::isfinite(x)) return 0; std::frexp(x, &e); return e; }
 inline float rsqf(float x) { return nudge(static_cast<float>(1.0 / std::sqrt(static_cast<double>(x)))); }
 inline float rcpf(float x) { return nudge(static_cast<float>(1.0 / static_cast<double>(x))); }
 inline float sqrtf_(float x) { return nudge(std::sqrt(x)); }
@@ -70,6 +72,7 @@ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return static_
 } // namespace rtk_shim
 
 #define __builtin_amdgcn_rsqf(x) rtk_shim::rsqf(x)
+#define __builtin_amdgcn_frexp_expf(x) rtk_shim::frexp_exp(x)
 #define __builtin_amdgcn_rcpf(x) rtk_shim::rcpf(x)
 #define __builtin_amdgcn_sqrtf(x) rtk_shim::sqrtf_(x)
 #define __builtin_amdgcn_sinf(x) rtk_shim::sin_rev(x)

@@ -69,13 +69,14 @@ class Emul:
             pass
 
     def scene_info(self):
-        b = np.zeros(4, np.float32)
+        b = np.zeros(8, np.float32)
         f = np.zeros(self.n, np.uint8)
         self._l.emul_scene_info(self._h, b.ctypes.data, f.ctypes.data)
-        return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2]), "scale": float(b[3])}, f
+        return {"c_max": float(b[0]), "r_max2": float(b[1]), "r_min": float(b[2]), "sigma": float(b[3]), "cls_cy": float(b[4]),
+                "cls_r2": float(b[5]), "acc_eps": float(b[6]), "kinds": int(b[7])}, f
 
     def class_words(self) -> int:
-        """Words of 32 spheres that got 8-byte class records (shared cy and radius); 0 on the staged path."""
+        """Words of 32 spheres that got a 16-term class tile (shared cy and radius); 0 on the staged path."""
         return int(self._l.emul_class_words(self._h))
 
     def grid_info(self):

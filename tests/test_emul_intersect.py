@@ -211,7 +211,7 @@ def test_unusual_ranges(stock_scene_golden, t_min, t_max):
     check(stock_scene_golden, rays, t_min, t_max, noises=(0,))
 
 
-# ---- class words (SceneDev::wdesc) and the horizontal basis e1 = (dz, 0, -dx) / h ------------------------------------
+# ---- class words (SceneDev::wdesc): words whose filterable spheres share the scene's most common (cy, radius) ----------
 def _class_scene(rng, n, y_groups, offset=(0.0, 0.0, 0.0), scale=1.0):
     """`n` spheres in list order: consecutive groups take their (cy, radius) from `y_groups` (None = random per sphere)."""
     cx = rng.uniform(-11, 11, n); cz = rng.uniform(-11, 11, n)
@@ -236,8 +236,9 @@ def test_stock_scene_is_fifteen_class_words_and_a_short_tail(stock_scene_golden)
     assert e.class_words() == 15
 
 
-@pytest.mark.parametrize("groups,n,want_words", [([(0.2, 0.2)], 96, 3), ([(0.2, 0.2), None, (1.0, 0.3)], 288, 6), ([None], 64, 0),
-                                                 ([(0.2, 0.2)], 40, 1), ([(-0.0, 0.25), (0.0, 0.25)], 64, 2)])
+@pytest.mark.parametrize("groups,n,want_words", [([(0.2, 0.2)], 96, 3), ([(0.2, 0.2), None, (1.0, 0.3)], 288, 3), ([None], 64, 0),
+                                                 ([(0.2, 0.2)], 40, 1), ([(-0.0, 0.25), (0.0, 0.25)], 64, 2),
+                                                 ([(0.2, 0.2), (1.0, 0.3), (1.0, 0.3)], 192, 4)])
 def test_class_words_parity_and_conservativeness(groups, n, want_words):
     rng = np.random.default_rng(n + len(groups))
     s = _class_scene(rng, n, groups)
@@ -248,14 +249,15 @@ def test_class_words_parity_and_conservativeness(groups, n, want_words):
     check(s, rays)
 
 
-def test_a_class_word_needs_one_radius_only():
-    """Class words share the r^2 term; the spheres' heights travel in the word's tile, so they may differ."""
+def test_a_class_word_shares_height_and_radius():
+    """A class word's tile holds the monomials of x and z only; cy and r^2 are folded into the ray's side, so both must
+    agree bit for bit (-0.0 is another height than 0.0)."""
     rng = np.random.default_rng(3)
-    s = _class_scene(rng, 32, [(0.0, 0.25)])
+    s = _class_scene(rng, 64, [(0.0, 0.25)])
+    assert Emul(s).class_words() == 2
     s["cy"][5] = np.float32(-0.0)
-    s["cy"][9] = np.float32(0.7)
     assert Emul(s).class_words() == 1
-    s["radius"][11] = np.float32(0.26)
+    s["radius"][40] = np.float32(0.26)
     assert Emul(s).class_words() == 0
     rays = np.concatenate([rng.uniform(-12, 12, (2000, 3)), rng.normal(size=(2000, 3))], 1).astype(np.float32)
     check(s, rays)
@@ -292,7 +294,8 @@ def test_translated_class_scene_far_from_the_origin():
 
 def test_tile_layout_helpers():
     """The word tiles of the matrix-pipe filter: the row -> sphere map is a permutation that hands each lane half 16
-    consecutive spheres, and a coordinate's three bf16 parts add up to it exactly."""
+    consecutive spheres; the f16 conversions of the host build are IEEE binary16 (numpy's); the term map covers every
+    monomial with the three part products (1,1), (1,2), (2,1)."""
     import ctypes as C
     lib = emul.lib(1)
     rows = [lib.emul_tile_row_sphere(r) for r in range(32)]
@@ -304,25 +307,45 @@ def test_tile_layout_helpers():
     for hf in range(2):
         for reg in range(16):
             assert rows[(reg & 3) + 8 * (reg >> 2) + 4 * hf] == 16 * hf + 8 * (reg & 1) + (reg >> 1)
-    lib.emul_bf16_split3_sum.restype = C.c_float
-    lib.emul_bf16_split3_sum.argtypes = [C.c_float]
+    lib.emul_f16_rne.restype = C.c_uint16
+    lib.emul_f16_rne.argtypes = [C.c_float]
+    lib.emul_f16_value.restype = C.c_float
+    lib.emul_f16_value.argtypes = [C.c_uint16]
     rng = np.random.default_rng(11)
-    for v in np.concatenate([rng.normal(size=2000) * 10.0 ** rng.uniform(-6, 18, 2000), [0.0, -0.0, 1.0, -1000.0, 0.2, 2.0 ** 60]]).astype(np.float32):
-        assert lib.emul_bf16_split3_sum(float(v)) == float(v)
+    vals = np.concatenate([rng.normal(size=4000) * 10.0 ** rng.uniform(-9, 5, 4000),
+                           [0.0, -0.0, 1.0, -1000.0, 0.2, 65504.0, 65519.9, 65520.0, 1e6, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 2.0 ** -14, 6.1e-5,
+                            2047.0, 2049.0, 2051.0, np.inf, -np.inf]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16)
+    for v, h in zip(vals, want):
+        bits = lib.emul_f16_rne(float(v))
+        assert bits == int(h.view(np.uint16)), (v, bits, h)
+        assert np.float32(lib.emul_f16_value(bits)).view(np.uint32) == np.float32(h).view(np.uint32)
+    out = (C.c_int * 3)()
+    for n_mono, kk in ((5, 16), (9, 32)):
+        seen = {}
+        for k in range(kk):
+            lib.emul_quad_term(k, n_mono, out)
+            if out[0] >= 0:
+                seen.setdefault(out[0], []).append((out[1], out[2]))
+        for m in range(n_mono):
+            assert seen[m] == [(0, 0), (0, 1), (1, 0)]
+        assert (seen.get(n_mono) == [(0, 0), (1, 0)]) == (n_mono == 9)
 
 
 def test_every_filter_test_is_exactly_zero_or_one(stock_scene_golden):
-    """The clamped value X = S^2 (r~^2 - p1^2 - p2^2) of a candidate must be exactly 1 (the bits are accumulated in fp32):
-    the scale is chosen so that it cannot fall inside (0, 1) (rtk_scene_prep.hpp)."""
+    """The clamped value X = -2^48 (D + K) of a candidate must be exactly 1 (the bits are accumulated in fp32): D and K are
+    multiples of 2^-48, so X cannot fall inside (0, 1) (rtk_intersect.hpp)."""
     e = Emul(stock_scene_golden)
     z = load_golden("rays_stock.npz")
     emul.wave_stats(1)
-    for batch in ("primary", "secondary", "grazing", "inside"):
+    for batch in ("primary", "secondary", "grazing", "inside", "degenerate"):
         e.intersect(z[batch + "_rays"][:4000])
     st = emul.wave_stats(1)
     assert st["filter_words"] > 0 and st["clamp_fractions"] == 0
     info, _ = e.scene_info()
-    assert info["scale"] == 2.0 ** 52                             # r~^2 = 0.04 (1+2^-15)^2: 2 s >= 98 - floor(log2 r~^2) = 103
+    assert info["sigma"] == 2.0 ** -4 and info["kinds"] == 1        # centres within 16 units; class words only
+    assert info["cls_cy"] == np.float32(0.2) / 16 and abs(info["cls_r2"] / (0.04 / 256) - 1) < 1e-4
 
 
 @pytest.mark.parametrize("n", [1, 5, 8, 9, 31, 32, 33, 40, 41, 64, 72, 73, 485])
