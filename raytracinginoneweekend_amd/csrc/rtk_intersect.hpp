@@ -23,6 +23,16 @@ namespace rtk {
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
 // Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
+// A 32x32 MFMA's result registers must not overlap its A or B operand (the matrix pipe reads them over several passes).
+// The compiler knows that for results in AGPRs; in the VGPR form this library is built with (-amdgpu-mfma-vgpr-form) it
+// has been seen to give the result tile the registers of an operand whose last use the MFMA is — frames then differed
+// from run to run (tools/determinism_check.py; tests/test_cabi.py checks the built code object for such overlaps).  This
+// empty statement reads the operands AFTER the results exist, so their registers cannot be reused for the results.
+#ifdef RTK_HOST_EMULATION
+#define RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, x, y) ((void)0)
+#else
+#define RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, x, y) asm volatile("" : "+v"(d0), "+v"(d1) : "v"(x), "v"(y))
+#endif
 #ifdef RTK_HOST_EMULATION
 #define RTK_SCHED_BARRIER() ((void)0)
 #else
@@ -234,11 +244,9 @@ struct Intersector {
             const bool short_tail = rem != 0 && rem <= kShortTail;
             const int words = short_tail ? full : full + (rem ? 1 : 0);       // words that have a tile
             uint32_t nz = 0;
-            auto keep = [&](int w, uint32_t m) {
-                if (m != 0) {
-                    masks[w * kWave + lane] = m;
-                    nz |= 0x80000000u >> w;
-                }
+            auto keep = [&](int w, uint32_t m) {          // the store is unconditional: nearly every word has a candidate on some lane
+                masks[w * kWave + lane] = m;
+                if (m != 0) nz |= 0x80000000u >> w;
             };
             const bool has_class = (fb.kinds & 1) != 0, has_general = (fb.kinds & 2) != 0;       // wave-uniform
             // ---- the ray's side of the dot product ----
@@ -357,10 +365,6 @@ struct Intersector {
                 }
                 __builtin_memcpy(&out[0], &g0, 16); __builtin_memcpy(&out[1], &g1, 16);
             };
-            f16x8 bc[2], bg0[2], bg1[2];
-            fragments(vc, bc);
-            fragments(vg, bg0);
-            fragments(vg + 16, bg1);
             float kcg[2], kgg[2];
             {
                 const u32x2 a1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(kc), __float_as_uint(kc), false, false);
@@ -368,7 +372,6 @@ struct Intersector {
                 kcg[0] = __uint_as_float(a1[0]); kcg[1] = __uint_as_float(a1[1]);
                 kgg[0] = __uint_as_float(a2[0]); kgg[1] = __uint_as_float(a2[1]);
             }
-            const int hf = lane >> 5;
             // Nothing this wave sent to the vector memory path earlier (the accumulator atomics of a retired unit, material
             // gathers) may still be queued when the matrix instructions start: such an instruction reads its address
             // registers late, and the compiler is free to make those registers part of an MFMA's result tile (seen on the
@@ -376,45 +379,73 @@ struct Intersector {
             __builtin_amdgcn_s_waitcnt(0x0F70);
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const float nbig = -0x1p48f;
-            for (int wi = 0; wi < words; ++wi) {
-                const float4 wd = wdesc[wi];
-                const bool cls = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y)) != 0;
-                const float4* tile = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
-                f32x16 dd[2];
-                float kk[2];
-                {
+            // 16 results of a lane -> 16 mask bits, first sphere in the highest bit: registers 2 m hold spheres 16 hf + m,
+            // registers 2 m + 1 spheres 16 hf + 8 + m; one fp32 accumulator (16 bits: exact)
+            auto bits16 = [&](const f32x16& d, float k) {
+                float acc = __builtin_amdgcn_fmed3f(fmaf(d[0], nbig, k), 0.0f, 1.0f);
+#pragma unroll
+                for (int e = 1; e < 16; ++e) {
+                    const int reg = e < 8 ? 2 * e : 2 * (e - 8) + 1;
+                    acc = fmaf(acc, 2.0f, __builtin_amdgcn_fmed3f(fmaf(d[reg], nbig, k), 0.0f, 1.0f));
+                }
+                return static_cast<uint32_t>(acc);
+            };
+            // h0 / h1: the 16 bits of this lane's spheres for the ray of lane (lane & 31) / (lane | 32).  After the swap a
+            // lane holds both halves of its own ray's word: spheres 0..15 (from the lower lane half) and 16..31.
+            auto join = [&](uint32_t h0, uint32_t h1) {
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(h0, h1, false, false);
+                return (sw[0] << 16) | sw[1];
+            };
+            if (!has_general) {
+                // every tile is a class tile: word w's fragments are filt[64 w ...]
+                f16x8 bc[2];
+                fragments(vc, bc);
+                for (int wi = 0; wi < words; ++wi) {
+                    const float4 wd = wdesc[wi];
+                    const float4 av = filt[wi * kWave + lane];
+                    f16x8 a0;
+                    __builtin_memcpy(&a0, &av, 16);
+                    f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
+                    f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
+                    RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a0, a0);
+                    const uint32_t m = join(bits16(d0, kcg[0]), bits16(d1, kcg[1]));
+                    RTK_STAT(lane, class_words);
+                    RTK_STAT(lane, filter_words);
+                    keep(wi, (m & __float_as_uint(wd.w)) | __float_as_uint(wd.z));
+                }
+            } else {
+                f16x8 bc[2], bg0[2], bg1[2];
+                fragments(vc, bc);
+                fragments(vg, bg0);
+                fragments(vg + 16, bg1);
+                for (int wi = 0; wi < words; ++wi) {
+                    const float4 wd = wdesc[wi];
+                    const bool cls = __builtin_amdgcn_readfirstlane(__float_as_int(wd.y)) != 0;
+                    const float4* tile = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
                     const float4 av = tile[lane];
                     f16x8 a0;
                     __builtin_memcpy(&a0, &av, 16);
+                    f32x16 d0, d1;
+                    float k0, k1;
                     if (cls) {
-                        dd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
-                        dd[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
-                        kk[0] = kcg[0]; kk[1] = kcg[1];
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
+                        k0 = kcg[0]; k1 = kcg[1];
                     } else {
                         const float4 av1 = tile[kWave + lane];
                         f16x8 a1;
                         __builtin_memcpy(&a1, &av1, 16);
-                        dd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[0], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[0], zero, 0, 0, 0), 0, 0, 0);
-                        dd[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[1], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[1], zero, 0, 0, 0), 0, 0, 0);
-                        kk[0] = kgg[0]; kk[1] = kgg[1];
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[0], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[0], zero, 0, 0, 0), 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[1], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[1], zero, 0, 0, 0), 0, 0, 0);
+                        k0 = kgg[0]; k1 = kgg[1];
+                        RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a1, a1);
                     }
+                    RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a0, a0);
+                    const uint32_t m = join(bits16(d0, k0), bits16(d1, k1));
+                    if (cls) RTK_STAT(lane, class_words);
+                    RTK_STAT(lane, filter_words);
+                    keep(wi, (m & __float_as_uint(wd.w)) | __float_as_uint(wd.z));
                 }
-                uint32_t half[2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    float acc_e = 0.0f, acc_o = 0.0f;          // registers 2 m: spheres 16 hf + m; registers 2 m + 1: spheres 16 hf + 8 + m
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        acc_e = fmaf(acc_e, 2.0f, __builtin_amdgcn_fmed3f(fmaf(dd[g][2 * m], nbig, kk[g]), 0.0f, 1.0f));
-                        acc_o = fmaf(acc_o, 2.0f, __builtin_amdgcn_fmed3f(fmaf(dd[g][2 * m + 1], nbig, kk[g]), 0.0f, 1.0f));
-                    }
-                    half[g] = ((static_cast<uint32_t>(acc_e) << 8) | static_cast<uint32_t>(acc_o)) << (hf ? 0 : 16);
-                }
-                // half[0] belongs to the ray of lane (lane & 31), half[1] to that of lane (lane | 32)
-                const u32x2 sw = __builtin_amdgcn_permlane32_swap(half[0], half[1], false, false);
-                if (cls) RTK_STAT(lane, class_words);
-                RTK_STAT(lane, filter_words);
-                keep(wi, ((sw[0] | sw[1]) & __float_as_uint(wd.w)) | __float_as_uint(wd.z));
             }
 #endif
             if (short_tail) {

@@ -100,3 +100,38 @@ def test_rccl_library_offers_what_rtk_multi_opens_on_demand():
     l = C.CDLL("librccl.so.1")
     for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
         assert hasattr(l, name), name
+
+
+def test_no_mfma_result_overlaps_its_operands(tmp_path):
+    """A 32x32 MFMA's result registers must not overlap its A or B operand, and its C operand only exactly (the matrix
+    pipe reads the operands over several passes).  Built with -amdgpu-mfma-vgpr-form the compiler has violated this (frames
+    differed from run to run on the GPU); rtk_intersect.hpp keeps the operands live past the results, and this test reads the
+    shipped code object to see that it worked."""
+    import re, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "raytracinginoneweekend_amd", "librtk.so")
+    if not (os.path.exists(lib) and os.path.exists(f"{llvm}/llvm-objdump")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "rtk.co")
+    subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    txt = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+
+    def regs(op):
+        m = re.fullmatch(r"([av])\[(\d+):(\d+)\]", op)
+        if m:
+            return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+        m = re.fullmatch(r"([av])(\d+)", op)
+        return (m.group(1), {int(m.group(2))}) if m else (None, set())
+
+    n = 0
+    for ln in txt.splitlines():
+        m = re.match(r"\s+(v_mfma_\S+)\s+([^/]+)", ln)
+        if not m:
+            continue
+        ops = [o.strip() for o in m.group(2).split(",")][:4]
+        (df, d), (af, a), (bf, b), (cf, c) = (regs(o) for o in ops)
+        n += 1
+        assert not (df == af and d & a) and not (df == bf and d & b), ln
+        assert not (df == cf and d & c) or d == c, ln
+    assert n >= 8          # the render and the intersect kernel: class loop and mixed loop
