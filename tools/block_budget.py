@@ -135,8 +135,9 @@ def make_classifier():
     r_end = anchor(R, "atomicAdd(A.stats + 0")
     i_calls = anchor(I, "RTK_STAT(lane, closest_hit_calls)")
     i_words = anchor(I, "auto scan_words = [&]()")
-    i_bfrag = anchor(I, "// B fragments: lane l supplies")
-    i_wordloop = next(n for n, ln in enumerate(open(I), 1) if n > i_bfrag and "for (int w = 0; w < words; ++w) {" in ln)
+    i_classloop = anchor(I, "if (!has_general) {")
+    i_mixedloop = anchor(I, "f16x8 bc[2], bg0[2], bg1[2];")
+    i_tail = anchor(I, "if (short_tail) {")
     i_unsafe = anchor(I, "// lanes whose ray the filter cannot judge")
     i_exact = anchor(I, "// exact stage: every lane pops")
     d_lambert = anchor(D, "if (type == 1) {")
@@ -161,9 +162,13 @@ def make_classifier():
                     return "exact: candidate pop (mask word -> index, loop control)"
                 if l >= i_unsafe:
                     return "filter: unsafe-ray override"
-                if l >= i_wordloop:
-                    return "filter: word loop (A fragment, 4 MFMA, 3 FMA per test, mask assembly and store)"
-                return "filter: per-pass ray vectors (bf16 splits, lane exchange)"
+                if l >= i_tail:
+                    return "filter: short last word on the vector ALUs (8 VALU per test)"
+                if l >= i_mixedloop:
+                    return "filter: word loop of scenes with general words (not entered on the stock scene)"
+                if l >= i_classloop:
+                    return "filter: class word loop (A fragment, 2 MFMA, 2 FMA per test, mask assembly and store)"
+                return "filter: per-pass ray coefficients (f16 splits, lane exchange)"
             return "filter: per-ray setup (basis, shrink factor)"
         if line < r_assign:
             return "refill: next sample of the run / flush the run's sums (3 x 64-bit atomic)"
@@ -215,8 +220,10 @@ def emulation_frequencies(width=96, height=64, spp=8):
         emul.lib(64).emul_force_staged(1)
     p = float(s["closest_hit_calls"])
     f = {
-        "filter: word loop (A fragment, 4 MFMA, 3 FMA per test, mask assembly and store)": s["filter_words"] / p,
-        "filter: per-pass ray vectors (bf16 splits, lane exchange)": 1.0,
+        "filter: class word loop (A fragment, 2 MFMA, 2 FMA per test, mask assembly and store)": s["filter_words"] / p,
+        "filter: word loop of scenes with general words (not entered on the stock scene)": 0.0,
+        "filter: short last word on the vector ALUs (8 VALU per test)": 1.0,
+        "filter: per-pass ray coefficients (f16 splits, lane exchange)": 1.0,
         "filter: word loop (descriptor, per-word constants, mask assembly and store)": s["filter_words"] / p,
         "filter: general tests of the partial last word": 1.0,
         "filter: per-ray setup (basis, shrink factor)": 1.0,
@@ -262,7 +269,7 @@ def main():
         b = blocks.setdefault(classify(chains[ad]), {"valu": 0, "cyc": 0, "salu": 0, "lds": 0, "vmem": 0, "slow": collections.Counter()})
         if op.startswith("v_mfma"):
             b["mfma"] = b.get("mfma", 0) + 1
-            b["cyc"] += 32                      # v_mfma_f32_32x32x16_bf16: 32 cycles of the SIMD, not overlapped with its vector instructions (tools/mfma_valu_overlap.hip)
+            b["cyc"] += 32                      # v_mfma_f32_32x32x16_f16: 32 cycles of the SIMD, not overlapped with its vector instructions (tools/mfma_valu_overlap.hip)
         elif op.startswith("v_"):
             c = issue_cycles(op)
             b["valu"] += 1
@@ -295,7 +302,7 @@ def main():
         dyn = b["cyc"] * fr
         slow = " ".join(f"{o}:{n}" for o, n in b["slow"].most_common(6))
         if b.get("mfma"):
-            slow = f"v_mfma_f32_32x32x16_bf16:{b['mfma']} (32 cycles each) " + slow
+            slow = f"v_mfma_f32_32x32x16_f16:{b['mfma']} (32 cycles each) " + slow
         L.append(f"| {k} | {b['valu']} | {b['cyc']} | {b['salu']} | {b['lds']} | {b['vmem']} | {fr:.2f} | {dyn:.0f} | {100 * dyn / total:.1f} % | {slow} |")
     L.append(f"| **sum** | {sum(b['valu'] for b in blocks.values())} | | | | | | **{total:.0f}** | 100 % | |")
     L.append("")

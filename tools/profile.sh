@@ -18,7 +18,8 @@ for PMC in \
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32" \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE GRBM_COUNT" \
-  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"
+  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
+  "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
 do
   i=$((i+1))
   echo "== pmc pass $i: $PMC"

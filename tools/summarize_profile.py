@@ -108,6 +108,9 @@ lines = [
     f"| effective clock | {clock_ghz:.2f} GHz | GRBM_GUI_ACTIVE / 8 / duration |",
     f"| VALU wave-instructions per launch | {valu:.3e} = {valu / wave_passes:.0f} per wavefront pass ({filt_txt}) | SQ_INSTS_VALU, passes = rays / 64 / lane utilisation ({roof['lane_utilisation']:.4f}) |",
     f"| VALU issue utilisation | {valu / N_SIMD * 2 / cyc if cyc else float('nan'):.3f} (2 cycles per wave64 VALU instruction per SIMD) | SQ_INSTS_VALU x 2 / (SIMDs x cycles) |",
+    f"| matrix pipe | busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / N_SIMD / cyc if cyc else float('nan'):.3f} of SIMD cycles = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 / wave_passes:.1f} MFMAs of 32 cycles per wavefront pass; "
+    f"executed f16 matrix flops {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 1e12:.0f} TF/s = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 2.5e15:.3f} of the 2.5 PF dense f16 peak; "
+    f"VALU + MFMA together occupy {(valu * 2 + g('SQ_VALU_MFMA_BUSY_CYCLES')) / N_SIMD / cyc if cyc else float('nan'):.3f} of the SIMDs' issue cycles (they do not overlap) | SQ_VALU_MFMA_BUSY_CYCLES |",
     f"| FP32 FMA / ADD / MUL / transcendental wave-instructions | {fma:.3e} / {add:.3e} / {mul:.3e} / {trans:.3e} | SQ_INSTS_VALU_* |",
     f"| EXECUTED fp32 flops (2 per FMA, 1 per ADD/MUL, x 64 lanes) as a fraction of the {PEAK_TF} TF peak | **{exec_frac:.3f}** (algorithmic-equivalent fraction above: {frac_trace:.3f}) | counters / duration |",
     f"| SALU / LDS / SMEM / VMEM wave-instructions | {g('SQ_INSTS_SALU'):.3e} / {g('SQ_INSTS_LDS'):.3e} / {g('SQ_INSTS_SMEM'):.3e} / {g('SQ_INSTS_VMEM'):.3e} | SQ_INSTS_* |",
