@@ -85,7 +85,9 @@ def test_headline_line(bench, monkeypatch, capsys):
     assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 1 and j["higher_is_better"] and j["scaling"] == "strong"
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None and "workload" in j["config"]
     r = j["roofline"]
-    assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and r["peak"] == bench.FP32_VECTOR_PEAK_TFLOPS
+    assert r["bound"].startswith("simd_issue") and r["unit"] == "TFLOP/s" and r["peak"] == bench.ISSUE_BOUND_PEAK_TFLOPS
+    assert abs(r["peak"] - 445.6) < 0.1 and r["fp32_vector_peak"] == bench.FP32_VECTOR_PEAK_TFLOPS
+    assert abs(r["frac_of_fp32_vector_peak"] - r["achieved"] / 157.3) < 1e-12
     # 1000 rays per 2 ms launch x 484 spheres x 17 flop
     assert r["rays_per_launch"] == 1000 and abs(r["kernel_ms"] - 2.0) < 1e-9
     assert abs(r["achieved"] - 1000 * 484 * 17 / 2e-3 / 1e12) < 1e-12 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-15

@@ -70,7 +70,9 @@ avg_ms = float(rk["AverageNs"]) / 1e6
 rays = roof["rays_per_launch"]
 wave_passes = rays / 64 / roof["lane_utilisation"]
 alg_flop = rays * roof["flop_per_ray"]
-frac_trace = alg_flop / (avg_ms * 1e-3) / 1e12 / PEAK_TF
+ROOF_PEAK = roof.get('peak', PEAK_TF)
+frac_trace = alg_flop / (avg_ms * 1e-3) / 1e12 / ROOF_PEAK
+frac_trace_vec = alg_flop / (avg_ms * 1e-3) / 1e12 / PEAK_TF
 # FETCH_SIZE / WRITE_SIZE are in units of 1024 B; gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM)
 fetch_b = pmc.get("FETCH_SIZE", 0.0) * 1024 * 2
 write_b = pmc.get("WRITE_SIZE", 0.0) * 1024
@@ -100,7 +102,7 @@ lines = [
     "| figure | value | how |",
     "|---|---|---|",
     f"| render_kernel average duration (kernel trace) | {avg_ms:.2f} ms over {rk['Calls']} calls ({rk['Percentage']} % of GPU time) | `{tag}_kernel_stats.csv` |",
-    f"| roofline fraction from the trace alone | {alg_flop:.4e} algorithmic flop per launch ({rays:.4e} rays x {roof['flop_per_ray']}) / {avg_ms:.2f} ms / {PEAK_TF} TF = **{frac_trace:.3f}** (bench line, HIP events: {roof['frac']:.3f}) | kernel trace + ray count of the traced run |",
+    f"| roofline fraction from the trace alone | {alg_flop:.4e} algorithmic flop per launch ({rays:.4e} rays x {roof['flop_per_ray']}) / {avg_ms:.2f} ms / {ROOF_PEAK:.1f} TF ({roof.get('bound')}) = **{frac_trace:.3f}** (bench line, HIP events: {roof['frac']:.3f}); against the {PEAK_TF} TF fp32 vector peak, the measure of rounds 1-2: {frac_trace_vec:.3f} | kernel trace + ray count of the traced run |",
     f"| launch | grid {grid.get('Grid_Size')} threads, workgroup {grid.get('Workgroup_Size')} | counter CSV |",
     f"| registers / LDS / scratch (code object) | {ck['vgpr_count']} VGPR + {ck['agpr_count']} AGPR, {ck['sgpr_count']} SGPR, spills {ck['vgpr_spill_count']} VGPR / {ck['sgpr_spill_count']} SGPR, static LDS {ck['group_segment_fixed_size']} B, "
     f"LDS per workgroup at launch {lds_wg} B, scratch {ck['private_segment_fixed_size']} B | `llvm-readelf --notes` of the profiled library (tools/code_object_info.py) |",
@@ -112,7 +114,7 @@ lines = [
     f"executed f16 matrix flops {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 1e12:.0f} TF/s = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 2.5e15:.3f} of the 2.5 PF dense f16 peak; "
     f"VALU + MFMA together occupy {(valu * 2 + g('SQ_VALU_MFMA_BUSY_CYCLES')) / N_SIMD / cyc if cyc else float('nan'):.3f} of the SIMDs' issue cycles (they do not overlap) | SQ_VALU_MFMA_BUSY_CYCLES |",
     f"| FP32 FMA / ADD / MUL / transcendental wave-instructions | {fma:.3e} / {add:.3e} / {mul:.3e} / {trans:.3e} | SQ_INSTS_VALU_* |",
-    f"| EXECUTED fp32 flops (2 per FMA, 1 per ADD/MUL, x 64 lanes) as a fraction of the {PEAK_TF} TF peak | **{exec_frac:.3f}** (algorithmic-equivalent fraction above: {frac_trace:.3f}) | counters / duration |",
+    f"| EXECUTED fp32 flops (2 per FMA, 1 per ADD/MUL, x 64 lanes) as a fraction of the {PEAK_TF} TF peak | **{exec_frac:.3f}** (algorithmic flops against the same peak: {frac_trace_vec:.3f}) | counters / duration |",
     f"| SALU / LDS / SMEM / VMEM wave-instructions | {g('SQ_INSTS_SALU'):.3e} / {g('SQ_INSTS_LDS'):.3e} / {g('SQ_INSTS_SMEM'):.3e} / {g('SQ_INSTS_VMEM'):.3e} | SQ_INSTS_* |",
     f"| LDS busy | {g('SQ_LDS_IDX_ACTIVE') / 256 / cyc if cyc else float('nan'):.3f} of kernel cycles per CU; bank-conflict cycles {g('SQ_LDS_BANK_CONFLICT') / max(1.0, g('SQ_LDS_IDX_ACTIVE')):.4f} of LDS cycles | SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT |",
     f"| wave time split | active {g('SQ_ACTIVE_INST_ANY') / wc:.3f}, waiting on issue {g('SQ_WAIT_INST_ANY') / wc:.3f}, parked (waitcnt) {g('SQ_WAIT_ANY') / wc:.3f} of SQ_WAVE_CYCLES | SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY |",
