@@ -133,7 +133,7 @@ struct Intersector {
         // A lane is "safe" when no intermediate of the filter can overflow, underflow to a wrong sign
         // or be NaN; unsafe lanes (NaN/inf/huge/zero-length rays) treat every sphere as a candidate.
         const float big = 0x1p30f;
-        FilterRay f;
+        FilterRay f = {};
         const float inv_len = __builtin_amdgcn_rsqf(a);
         // Orthonormal basis (e1, e2) of the plane perpendicular to the ray with e1 horizontal:
         //   e1 = (dz, 0, -dx) / h,  e2 = d x e1 = (-dx dy / h, h, -dy dz / h),  h = sqrt(dx^2 + dz^2)   (d = unit direction).
@@ -142,17 +142,17 @@ struct Intersector {
         // direction and tests every sphere.  A sphere can only be hit if its centre, projected on that plane, lies
         // within r of the ray.  The projected distances are shrunk by g < 1 so that everything the reference's own
         // rounding could still accept (E) and this filter's evaluation error (dp) stay inside r.
-        // (LDS-resident scenes use this form for a short last word only.)
+        // (Scenes beyond LDS only; LDS-resident scenes use the dot-product form below.)
         const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
         const float h2 = fmaf(dx, dx, dz * dz);
         const float inv_h = __builtin_amdgcn_rsqf(h2);
         const float o_len = __builtin_amdgcn_sqrtf(fmaf(r.o.x, r.o.x, fmaf(r.o.y, r.o.y, r.o.z * r.o.z)));
         // the dot-product form scales the ray's coefficients by 2^-2k, 2^k > sigma |o|, k <= 12
-        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f) && (h2 > 0x1p-40f) &&
-                          (!LDS || fb.sigma * o_len < 0x1p12f);
-        const float u1x = dz * inv_h, u1z = -dx * inv_h;                     // unshrunk basis
-        const float u2x = -dy * (dx * inv_h), u2y = h2 * inv_h, u2z = -dy * (dz * inv_h);
-        {
+        const bool safe = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f) &&
+                          (LDS ? fb.sigma * o_len < 0x1p12f : h2 > 0x1p-40f);
+        if (!LDS) {
+            const float u1x = dz * inv_h, u1z = -dx * inv_h;                     // unshrunk basis
+            const float u2x = -dy * (dx * inv_h), u2y = h2 * inv_h, u2z = -dy * (dz * inv_h);
             const float M = o_len + fb.c_max;
             const float E = 0x1p-19f * fmaf(M, M, fb.r_max2);
             const float dp = 0x1p-19f * M;          // this form's own error in a projected coordinate: three FMA roundings
@@ -282,7 +282,8 @@ struct Intersector {
             };
             const float cy = fb.cls_cy;
             const float kc = constant(fmaf(fmaf(-2.0f * py, cy, fmaf(qyy, cy * cy, pp)) - fb.cls_r2, t, -marg));
-            const float kg = constant(fmaf(pp, t, -marg));
+            const float kt = fmaf(pp, t, -marg);          // the general constant, t-scaled
+            const float kg = constant(kt);
             // term vectors (quad_term): class xx zz xz x z; general xx yy zz xy xz yz x y z, then r'^2 against -t
             uint16_t vc[16], vg[32];
             if (has_class) {
@@ -300,11 +301,12 @@ struct Intersector {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) vc[k] = 0;
             }
+            // the general coefficients, t-scaled, in fp32: for general tiles (times 2^13, split) and for the short tail (as they are)
+            const float cg[kQuadGeneralMonomials + 1] = {qxx * t, qyy * t, qzz * t, qxy * t, qxz * t, qyz * t, -2.0f * px * t, -2.0f * py * t, -2.0f * pz * t, -t};
             if (has_general) {
-                const float co[kQuadGeneralMonomials + 1] = {qxx * tb, qyy * tb, qzz * tb, qxy * tb, qxz * tb, qyz * tb, -2.0f * px * tb, -2.0f * py * tb, -2.0f * pz * tb, -tb};
                 uint16_t parts[kQuadGeneralMonomials + 1][2];
 #pragma unroll
-                for (int m = 0; m <= kQuadGeneralMonomials; ++m) f16_split2(co[m], parts[m]);
+                for (int m = 0; m <= kQuadGeneralMonomials; ++m) f16_split2(cg[m] * kQuadRayScale, parts[m]);
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
                     int mono, sp, rp;
@@ -314,6 +316,25 @@ struct Intersector {
             } else {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) vg[k] = 0;
+            }
+            if (short_tail) {          // before the word loops: the fp32 coefficients need not live through them
+                // the few spheres of the last word, on the vector ALUs: the same dot product from fp32 monomials (three
+                // float4 per sphere: xx yy zz xy | xz yz x y | z r'^2 - -) and the fp32 coefficients, 11 FMAs, each
+                // within 2^-24 T: inside the margin's allowance for the matrix pipe's 16 steps; the sign is the result.
+                // A sphere the filter must not reject has r'^2 = +inf.
+                const float4 wd = wdesc[full];
+                const float4* q = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
+                uint32_t m = 0;
+                for (int i = 0; i < rem; ++i) {
+                    const float4 ma = q[3 * i], mb = q[3 * i + 1], mc = q[3 * i + 2];
+                    float acc = fmaf(ma.x, cg[0], kt);
+                    acc = fmaf(ma.y, cg[1], acc); acc = fmaf(ma.z, cg[2], acc); acc = fmaf(ma.w, cg[3], acc);
+                    acc = fmaf(mb.x, cg[4], acc); acc = fmaf(mb.y, cg[5], acc); acc = fmaf(mb.z, cg[6], acc); acc = fmaf(mb.w, cg[7], acc);
+                    acc = fmaf(mc.x, cg[8], acc); acc = fmaf(mc.y, cg[9], acc);
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc), 31);
+                }
+                RTK_STAT(lane, tail_tests);
+                keep(full, (m << (32 - rem)) | __float_as_uint(wd.z));
             }
 #ifdef RTK_HOST_EMULATION
             // CPU build: the same part products summed in fp32, sphere by sphere (the matrix pipe's own summation order is
@@ -448,20 +469,6 @@ struct Intersector {
                 }
             }
 #endif
-            if (short_tail) {
-                // the few spheres of the last word, on the vector ALUs: the sign of p1^2 + p2^2 - r~^2, shifted into the word
-                const float4 wd = wdesc[full];
-                const float4* q = filt + __builtin_amdgcn_readfirstlane(__float_as_int(wd.x));
-                uint32_t m = 0;
-                for (int i = 0; i < rem; ++i) {
-                    const float4 sp = q[i];
-                    const float p1 = fmaf(sp.z, f.e1z, fmaf(sp.x, f.e1x, f.ns1));
-                    const float p2 = fmaf(sp.z, f.e2z, fmaf(sp.y, f.e2y, fmaf(sp.x, f.e2x, f.ns2)));
-                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(fmaf(p2, p2, fmaf(p1, p1, -sp.w))), 31);
-                }
-                RTK_STAT(lane, tail_tests);
-                keep(full, (m << (32 - rem)) | __float_as_uint(wd.z));
-            }
             // lanes whose ray the filter cannot judge test every sphere (rare: one vote per ray, outside the word loop)
             if (wave_any(active && !safe)) {
                 if (!safe) {

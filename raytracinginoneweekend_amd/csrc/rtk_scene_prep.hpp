@@ -161,7 +161,17 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             int32_t kind;
             if (w >= tile_words) {           // short tail: plain records behind the tiles, tested on the vector ALUs
                 kind = 2;
-                for (int i = base; i < n; ++i) tiles.push_back(filterable[i] ? make_float4(s->cx[i], s->cy[i], s->cz[i], widened_r2(i)) : make_float4(0.f, 0.f, 0.f, -inf));
+                for (int i = base; i < n; ++i) {             // three float4 per sphere: fp32 monomials of the scaled centre, r'^2
+                    if (!filterable[i]) {                    // never rejected: r'^2 = +inf drives the sum to -inf
+                        tiles.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); tiles.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); tiles.push_back(make_float4(0.f, inf, 0.f, 0.f));
+                        continue;
+                    }
+                    const double x = sigma * s->cx[i], y = sigma * s->cy[i], z = sigma * s->cz[i];
+                    const float r2 = static_cast<float>(sigma * sigma * widened_r2(i)) * (1.0f + 0x1p-20f);     // rounded up
+                    tiles.push_back(make_float4(static_cast<float>(x * x), static_cast<float>(y * y), static_cast<float>(z * z), static_cast<float>(x * y)));
+                    tiles.push_back(make_float4(static_cast<float>(x * z), static_cast<float>(y * z), static_cast<float>(x), static_cast<float>(y)));
+                    tiles.push_back(make_float4(static_cast<float>(z), r2, 0.f, 0.f));
+                }
             } else {
                 const bool cls = word_key[w] >= 0 && word_key[w] == cls_key;
                 kind = cls ? 1 : 0;
