@@ -13,6 +13,6 @@ for i in range(n):
     img, st = ctx.render(cam, W, H, spp, 50, seed=11)
     h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
     seen[h] = seen.get(h, 0) + 1
-    print(i, h, st["rays"], st["exact_tests"], flush=True)
+    print(i, h, st["rays"], st["exact_tests"], st.get("samples"), st.get("lane_slots"), flush=True)
 print(os.environ.get("RTK_LIB", "in-tree"), "distinct images:", len(seen))
 sys.exit(0 if len(seen) == 1 else 1)
