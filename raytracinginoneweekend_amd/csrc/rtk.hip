@@ -563,6 +563,7 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
     int tw, th;
     if (int e = norm_tiles(p, tw, th)) return e;
     if (static_cast<int64_t>(p->width) * p->height >= (1ll << 31)) return fail(RTK_ERR_TOO_LARGE, "image has more than 2^31 pixels");
+    if (p->width > 65535 || p->height > 65535) return fail(RTK_ERR_TOO_LARGE, "image %d x %d: width and height are limited to 65535 (the kernel packs a pixel's column and row into one register)", p->width, p->height);
     HIP_TRY(hipSetDevice(c->device));
 
     const int tiles_x = (p->width + tw - 1) / tw;

@@ -119,6 +119,13 @@ struct FilterBounds {
     float cls_r2;    // their scaled, widened r'^2
     float acc_eps;   // relative bound of the matrix pipe's evaluation error for this scene's word kinds (kQuadEpsClass / General)
     int32_t kinds;   // bit 0: the scene has class words, bit 1: general words
+    // products of the above that the margin needs per ray, made on the host: as kernel arguments they are scalar operands,
+    // computed in the kernel they were loop invariants held in vector registers for the life of the kernel
+    float cp;        // c' = sigma c_max (<= 1)
+    float cp_twice;  // 2 c'
+    float rp2;       // r'max^2 = sigma^2 r_max2
+    float t_quad;    // sqrt(2) c'^2 + r'max^2, rounded up
+    float cls_cy2;   // cls_cy^2
 };
 
 struct SceneDev {
@@ -251,6 +258,12 @@ __device__ __forceinline__ unsigned long long rtk_wall_clock() { return wall_clo
 // Wave-level helpers (wave64).
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// sum of a small per-lane count over the wave, by votes on its bits (every lane gets the total)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    uint32_t s = 0;
+    for (int b = 0; b < 32 && wave_any((v >> b) != 0u); ++b) s += static_cast<uint32_t>(__popcll(__ballot(((v >> b) & 1u) != 0u))) << b;
+    return s;
+}
 __device__ __forceinline__ int lane_prefix(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
 }

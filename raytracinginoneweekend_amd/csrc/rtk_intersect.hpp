@@ -100,6 +100,7 @@ struct Intersector {
                                           uint32_t& n_exact) const {
         for (int k = 0; wave_any(k < cnt); ++k) {
             RTK_STAT(lane, flush_iters);
+            n_exact += static_cast<uint32_t>(__popcll(ballot(k < cnt)));
             if (k < cnt) {
                 const int j = list_base + static_cast<int>(list[k * kWave + lane]);
                 const float4 s = exact[j];
@@ -108,7 +109,7 @@ struct Intersector {
                     closest = root;
                     best = j;
                 }
-                ++n_exact;
+                
             }
         }
         cnt = 0;
@@ -126,6 +127,7 @@ struct Intersector {
         const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
         m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
     }
+    // `n_exact`: the WAVE's running total of exact tests (every lane holds the same number).
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
                                                 uint32_t& n_exact) const {
         // Reference `a` (Sphere3.hpp:33), hoisted.
@@ -246,7 +248,11 @@ struct Intersector {
             uint32_t nz = 0;
             auto keep = [&](int w, uint32_t m) {          // the store is unconditional: nearly every word has a candidate on some lane
                 masks[w * kWave + lane] = m;
+#ifdef RTK_X0
+                nz |= (m != 0 ? 1u : 0u) << (31 - w);
+#else
                 if (m != 0) nz |= 0x80000000u >> w;
+#endif
             };
             const bool has_class = (fb.kinds & 1) != 0, has_general = (fb.kinds & 2) != 0;       // wave-uniform
             // ---- the ray's side of the dot product ----
@@ -268,10 +274,9 @@ struct Intersector {
             // own |o - C|^2 + r^2:  what the reference's rounding could still accept is 2^-19 T1, this
             // evaluation is within acc_eps T + 2^-22 of the true value (rtk_device.hpp kQuadEps*; 2^-22: f16 parts below
             // the normal range, should the matrix pipe flush them).
-            const float cp = sg * fb.c_max, rp2 = sg * sg * fb.r_max2;
             const float w = ol * tk;
-            const float T = fmaf(fmaf(1.42f * cp, cp, rp2), t, fmaf(2.0f * cp, tk, w) * w);
-            const float T1 = fmaf(fmaf(tk, cp, w), fmaf(tk, cp, w), rp2 * t);
+            const float T = fmaf(fb.t_quad, t, fmaf(fb.cp_twice, tk, w) * w);
+            const float T1 = fmaf(fmaf(tk, fb.cp, w), fmaf(tk, fb.cp, w), fb.rp2 * t);
             const float marg = 1.25f * fmaf(fb.acc_eps, T, 0x1p-19f * T1) + 0x1p-21f;
             const float tb = t * kQuadRayScale;
             // constants: K t 2^27, pushed away from zero so that it is a multiple of 2^-48, then times -2^48
@@ -281,7 +286,7 @@ struct Intersector {
                 return ks * -0x1p48f;
             };
             const float cy = fb.cls_cy;
-            const float kc = constant(fmaf(fmaf(-2.0f * py, cy, fmaf(qyy, cy * cy, pp)) - fb.cls_r2, t, -marg));
+            const float kc = constant(fmaf(fmaf(-2.0f * py, cy, fmaf(qyy, fb.cls_cy2, pp)) - fb.cls_r2, t, -marg));
             const float kt = fmaf(pp, t, -marg);          // the general constant, t-scaled
             const float kg = constant(kt);
             // term vectors (quad_term): class xx zz xz x z; general xx yy zz xy xz yz x y z, then r'^2 against -t
@@ -501,6 +506,7 @@ struct Intersector {
                     m = masks[w * kWave + lane];
                     wb = w << 5;
                 }
+                n_exact += static_cast<uint32_t>(__popcll(ballot(m != 0)));
                 if (m != 0) {
                     const int pos = __clz(static_cast<int>(m));
                     m &= ~(0x80000000u >> pos);
@@ -511,7 +517,7 @@ struct Intersector {
                         closest = root;
                         best = j;
                     }
-                    ++n_exact;
+                    
                 }
             }
 #ifdef RTK_PROFILE_SECTIONS
@@ -578,6 +584,7 @@ struct Intersector {
         const bool use = active && safe;
         float closest = t_max;
         int best = -1;
+        uint32_t mine = 0;          // this lane's exact tests (the walk below is divergent); added to the wave's total at the end
         auto test = [&](int j) {
             const float4 s = exact[j];
             float root;
@@ -585,7 +592,7 @@ struct Intersector {
                 closest = root;
                 best = j;
             }
-            ++n_exact;
+            ++mine;
         };
         for (int k = 0; k < G.n_always; ++k) {             // the same sphere on every lane: broadcast loads
             const int j = static_cast<int>(G.always[k]);
@@ -637,6 +644,7 @@ struct Intersector {
                 }
             }
         }
+        n_exact += wave_sum(mine);
         const bool brute = active && !safe;
         if (wave_any(brute)) {
             float t2;

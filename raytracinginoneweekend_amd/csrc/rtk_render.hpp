@@ -68,10 +68,11 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;      // this unit's colour sums, 32.32 fixed point
     bool alive = false, has_unit = false;
     int depth_left = 0, unit_left = 0;
-    uint32_t pixel = 0, slot = 0, sample = 0, bounce = 0;
-    int px = 0, prow = 0;
-    uint32_t n_seg = 0, n_samp = 0, n_exact = 0;
+    uint32_t slot = 0, sample = 0;
+    uint32_t pxy = 0;            // pixel column | row << 16 (rtk_render_tiles checks W, H <= 65535); the pixel index and the bounce number
+                                 // are re-derived where they are needed: every register that lives through the loop counts (128 per lane)
     // wave state (uniform)
+    uint32_t n_seg = 0, n_samp = 0, n_exact = 0;      // totals of the wave (votes), not per lane
     int pk_pos = kTilePixels, pk_lt = 0, pk_x0 = 0, pk_y0 = 0;
     uint32_t pk_first = 0, pk_len = 1, pk_next = 0, pk_end = 0;
     bool queue_empty = false;
@@ -137,10 +138,10 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             const int r = lane_prefix(nb);
             if (need && r < avail) {
                 const int k = pk_pos + r;
-                px = pk_x0 + (k & (A.tile_w - 1));
-                prow = pk_y0 + (k >> A.tile_w_log2);
+                const int px = pk_x0 + (k & (A.tile_w - 1));
+                const int prow = pk_y0 + (k >> A.tile_w_log2);
                 if (px < A.W && prow < A.H) {
-                    pixel = static_cast<uint32_t>(prow) * static_cast<uint32_t>(A.W) + static_cast<uint32_t>(px);
+                    pxy = static_cast<uint32_t>(px) | (static_cast<uint32_t>(prow) << 16);
                     slot = static_cast<uint32_t>(pk_lt) * kTilePixels + static_cast<uint32_t>(k);
                     sample = pk_first + A.sample_offset;
                     unit_left = static_cast<int>(pk_len) - 1;
@@ -156,16 +157,26 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         }
         // ---- primary rays (main.cpp:69-71) ----
         RTK_STAT_ANY(lane, pass_start_block, start);
+        n_samp += static_cast<uint32_t>(__popcll(ballot(start)));
+        // the global pixel index, re-derived at each use (the empty statement keeps the compiler from carrying the first
+        // result through the intersection in a register)
+        auto pixel_index = [&]() {
+            uint32_t q = pxy;
+#ifndef RTK_HOST_EMULATION
+            asm volatile("" : "+v"(q));
+#endif
+            return (q >> 16) * static_cast<uint32_t>(A.W) + (q & 0xFFFFu);
+        };
         if (start) {
+            const int px = static_cast<int>(pxy & 0xFFFFu), prow = static_cast<int>(pxy >> 16);
+            const uint32_t pixel = pixel_index();
             const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
             const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
             asm volatile("" ::: "memory");      // keep the camera reads in this block (hoisted, they would occupy 22 VGPRs for the whole loop)
             ray = primary_ray(*cam, px, prow, A.W, A.H, u);
             thr = {1.0f, 1.0f, 1.0f};
             depth_left = A.max_depth;
-            bounce = 0;
             alive = depth_left > 0;   // main.cpp:87-89: depth <= 0 gathers no light and traces nothing
-            ++n_samp;
         }
         if (!wave_any(alive)) {
             if (!wave_any(has_unit)) break;
@@ -187,12 +198,12 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             RTK_STAT_ANY(lane, pass_glass, ty_ == 3);
         }
 #endif
+        n_seg += static_cast<uint32_t>(__popcll(ballot(alive)));
         if (alive) {
             // unit_vector(r.direction()) of main.cpp:98 / Material.cpp:22,36 — one evaluation serves sky, metal and glass
             const V3 ud = unit_vector(ray.d);
-            ++n_seg;
 #ifdef RTK_HOST_EMULATION
-            if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel) * A.spp + (sample - A.sample_offset)];
+            if (A.dbg_seg) ++A.dbg_seg[static_cast<size_t>(pixel_index()) * A.spp + (sample - A.sample_offset)];
 #endif
             if (idx < 0) {
                 const V3 c = thr * sky_unit(ud);           // main.cpp:98-100: the only non-zero outcome of a path
@@ -201,8 +212,8 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 acc_b += to_fixed_32_32(c.z);
                 alive = false;
             } else {
-                ++bounce;
-                const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, bounce, 0u), key);
+                const uint32_t bounce = static_cast<uint32_t>(A.max_depth - depth_left) + 1u;      // 1 for the first hit of a path
+                const uint4 rnd = philox4x32_10(make_uint4(pixel_index(), sample, bounce, 0u), key);
                 const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
                 const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
                 Ray out;
@@ -223,10 +234,10 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                static_cast<double>(total - isect.prof[0] - isect.prof[1]) / wave_passes);
     }
 #endif
-    atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
-    atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
-    atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
     if (lane == 0) {
+        atomicAdd(A.stats + 0, static_cast<unsigned long long>(n_seg));
+        atomicAdd(A.stats + 1, static_cast<unsigned long long>(n_samp));
+        atomicAdd(A.stats + 2, static_cast<unsigned long long>(n_exact));
         atomicAdd(A.stats + 3, static_cast<unsigned long long>(wave_passes));
         atomicMax(A.stats + 4, static_cast<unsigned long long>(wave_passes));
         // kernel start (earliest), first and last wave to run out of work: ~t so that the zeroed counter is the identity of max

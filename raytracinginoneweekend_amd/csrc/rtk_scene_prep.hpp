@@ -65,7 +65,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         volatile float rr_v = s->radius[i] * s->radius[i];
         return static_cast<float>(rr_v) * kFilterScaleSq;
     };
-    FilterBounds fb = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, kQuadEpsClass, 0};
+    FilterBounds fb = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, kQuadEpsClass, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (!order.empty()) {
         fb.r_min = inf;
         for (int i : order) {
@@ -210,6 +210,14 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         }
         fb.kinds = (out.class_words ? 1 : 0) | (any_general ? 2 : 0);
         fb.acc_eps = any_general ? kQuadEpsGeneral : kQuadEpsClass;
+        {
+            const double cpd = sigma * fb.c_max, rp2d = sigma * sigma * fb.r_max2, up = 1.0 + 1e-6;       // rounded up: they widen the margin
+            fb.cp = static_cast<float>(cpd * up);
+            fb.cp_twice = static_cast<float>(2.0 * cpd * up);
+            fb.rp2 = static_cast<float>(rp2d * up);
+            fb.t_quad = static_cast<float>((1.42 * cpd * cpd + rp2d) * up);
+            fb.cls_cy2 = fb.cls_cy * fb.cls_cy;
+        }
         out.fb = fb;
         out.filt_lds = static_cast<int>(tiles.size());
         filt = tiles;

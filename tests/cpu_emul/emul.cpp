@@ -169,7 +169,8 @@ void emul_intersect(void* h, const float* rays, uint64_t n, float t_min, float t
                 t[i] = idx >= 0 ? tt : 0.0f;
             }
         });
-        for (int l = 0; l < kWave; ++l) { total += ne_lane[l]; ne_lane[l] = 0; }
+        total += ne_lane[0];          // closest_hit counts per wave: every lane holds the wave's total
+        for (int l = 0; l < kWave; ++l) ne_lane[l] = 0;
     }
     fold_stats();
     if (n_exact_total) *n_exact_total = total;

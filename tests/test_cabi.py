@@ -135,3 +135,22 @@ def test_no_mfma_result_overlaps_its_operands(tmp_path):
         assert not (df == af and d & a) and not (df == bf and d & b), ln
         assert not (df == cf and d & c) or d == c, ln
     assert n >= 8          # the render and the intersect kernel: class loop and mixed loop
+
+
+def test_render_kernels_use_no_scratch_memory():
+    """No kernel of the library may spill vector registers to scratch memory.  Builds of the LDS render kernel that did (5-12
+    registers at the 128-register cap) rendered frames that differed from run to run as soon as three or more workgroups
+    shared a CU, while the same source without spills (a larger register budget) or with at most two workgroups per CU was
+    exact (profiles/r02q_determinism_notes.md); SGPR spills to VGPR lanes are fine."""
+    import json, subprocess, sys
+    lib = os.path.join(ROOT, "raytracinginoneweekend_amd", "librtk.so")
+    if not (os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "code_object_info.py"), lib, "--json"], check=True, capture_output=True, text=True).stdout
+    info = json.loads(out)
+    kernels = info if isinstance(info, list) else info.get("kernels", info)
+    seen = 0
+    for k in (kernels.values() if isinstance(kernels, dict) else kernels):
+        seen += 1
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    assert seen >= 10
