@@ -138,10 +138,9 @@ def test_no_mfma_result_overlaps_its_operands(tmp_path):
 
 
 def test_render_kernels_use_no_scratch_memory():
-    """No kernel of the library may spill vector registers to scratch memory.  Builds of the LDS render kernel that did (5-12
-    registers at the 128-register cap) rendered frames that differed from run to run as soon as three or more workgroups
-    shared a CU, while the same source without spills (a larger register budget) or with at most two workgroups per CU was
-    exact (profiles/r02q_determinism_notes.md); SGPR spills to VGPR lanes are fine."""
+    """No kernel of the library spills vector registers to scratch memory (the LDS render kernel sits exactly at the 128
+    registers that four waves per SIMD allow; a change that pushes it over shows up here, not as a slower kernel).  SGPR
+    spills to VGPR lanes are fine."""
     import json, subprocess, sys
     lib = os.path.join(ROOT, "raytracinginoneweekend_amd", "librtk.so")
     if not (os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")):
