@@ -200,10 +200,12 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # only a measurement of THIS kernel build counts (the tag is bumped whenever the kernel's memory behaviour changes)
-                traffic = tj.get("bytes_per_launch") if tj.get("kernel_tag") == KERNEL_TAG else None
+                traffic = tj.get("bytes_per_launch") if tj.get("kernel_tag") == KERNEL_TAG else None      # measured on configs[1] at one GPU: see below
             except Exception:
                 traffic = None
         headline = args.scene_k <= 0 and args.accel == "list"
+        if not (headline and world == 1 and (args.width, args.height, args.spp) == (1200, 800, 500)):
+            traffic = None          # the counters were collected on configs[1] at one GPU only
         lay = ctx.scene_layout()
         n_class = 32 * lay["class_words"]
         on_matrix_pipe = n_spheres <= 1024

@@ -131,13 +131,14 @@ def make_classifier():
     r_seg = anchor(R, "// ---- one segment")
     r_alive = anchor(R, "if (alive) {")
     r_sky = anchor(R, "if (idx < 0) {")
-    r_hit = anchor(R, "++bounce;")
+    r_hit = anchor(R, "const uint32_t bounce = static_cast<uint32_t>(A.max_depth - depth_left) + 1u;")
     r_end = anchor(R, "atomicAdd(A.stats + 0")
     i_calls = anchor(I, "RTK_STAT(lane, closest_hit_calls)")
     i_words = anchor(I, "auto scan_words = [&]()")
     i_classloop = anchor(I, "if (!has_general) {")
     i_mixedloop = anchor(I, "f16x8 bc[2], bg0[2], bg1[2];")
-    i_tail = anchor(I, "if (short_tail) {")
+    i_tail = anchor(I, "if (short_tail) {          // before the word loops")
+    i_bfrag = anchor(I, "// B fragments: lane l supplies")
     i_unsafe = anchor(I, "// lanes whose ray the filter cannot judge")
     i_exact = anchor(I, "// exact stage: every lane pops")
     d_lambert = anchor(D, "if (type == 1) {")
@@ -162,14 +163,16 @@ def make_classifier():
                     return "exact: candidate pop (mask word -> index, loop control)"
                 if l >= i_unsafe:
                     return "filter: unsafe-ray override"
-                if l >= i_tail:
-                    return "filter: short last word on the vector ALUs (8 VALU per test)"
                 if l >= i_mixedloop:
                     return "filter: word loop of scenes with general words (not entered on the stock scene)"
                 if l >= i_classloop:
                     return "filter: class word loop (A fragment, 2 MFMA, 2 FMA per test, mask assembly and store)"
+                if l >= i_bfrag:
+                    return "filter: per-pass ray coefficients (f16 splits, lane exchange)"
+                if l >= i_tail:
+                    return "filter: short last word on the vector ALUs (11 FMA per test)"
                 return "filter: per-pass ray coefficients (f16 splits, lane exchange)"
-            return "filter: per-ray setup (basis, shrink factor)"
+            return "filter: per-ray setup (unit direction, safety)"
         if line < r_assign:
             return "refill: next sample of the run / flush the run's sums (3 x 64-bit atomic)"
         if line < r_start:
@@ -222,11 +225,11 @@ def emulation_frequencies(width=96, height=64, spp=8):
     f = {
         "filter: class word loop (A fragment, 2 MFMA, 2 FMA per test, mask assembly and store)": s["filter_words"] / p,
         "filter: word loop of scenes with general words (not entered on the stock scene)": 0.0,
-        "filter: short last word on the vector ALUs (8 VALU per test)": 1.0,
+        "filter: short last word on the vector ALUs (11 FMA per test)": 1.0,
         "filter: per-pass ray coefficients (f16 splits, lane exchange)": 1.0,
         "filter: word loop (descriptor, per-word constants, mask assembly and store)": s["filter_words"] / p,
         "filter: general tests of the partial last word": 1.0,
-        "filter: per-ray setup (basis, shrink factor)": 1.0,
+        "filter: per-ray setup (unit direction, safety)": 1.0,
         "filter: unsafe-ray override": 0.0,
         "exact: root test (Sphere3.hpp:31-49)": s["flush_iters"] / p,
         "exact: candidate pop (mask word -> index, loop control)": s["flush_iters"] / p,
