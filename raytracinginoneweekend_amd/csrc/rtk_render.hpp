@@ -59,7 +59,16 @@ __device__ __forceinline__ unsigned long long to_fixed_32_32(float f) {
 template <bool LDS, bool GRID = false>
 __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersector<LDS>& isect, const CameraDev* cam, const GridDev* grid = nullptr) {
     const int lane = isect.lane;
-    const uint2 key = make_uint2(A.seed_lo, A.seed_hi);
+    // The Philox key as the generator sees it: taken through an empty statement at every call, so that the ten round keys
+    // are formed by scalar adds where they are used.  As loop invariants they were twenty scalar registers for the life
+    // of the kernel, spilled to lanes of a vector register and read back with v_readlane in every pass.
+    auto philox_key = [&]() {
+        uint32_t k0 = A.seed_lo, k1 = A.seed_hi;
+#ifndef RTK_HOST_EMULATION
+        asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
+        return make_uint2(k0, k1);
+    };
     const unsigned long long t_begin = rtk_wall_clock();
 
     // lane state
@@ -170,7 +179,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
         if (start) {
             const int px = static_cast<int>(pxy & 0xFFFFu), prow = static_cast<int>(pxy >> 16);
             const uint32_t pixel = pixel_index();
-            const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), key);
+            const uint4 rnd = philox4x32_10(make_uint4(pixel, sample, 0u, 0u), philox_key());
             const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
             asm volatile("" ::: "memory");      // keep the camera reads in this block (hoisted, they would occupy 22 VGPRs for the whole loop)
             ray = primary_ray(*cam, px, prow, A.W, A.H, u);
@@ -213,7 +222,7 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
                 alive = false;
             } else {
                 const uint32_t bounce = static_cast<uint32_t>(A.max_depth - depth_left) + 1u;      // 1 for the first hit of a path
-                const uint4 rnd = philox4x32_10(make_uint4(pixel_index(), sample, bounce, 0u), key);
+                const uint4 rnd = philox4x32_10(make_uint4(pixel_index(), sample, bounce, 0u), philox_key());
                 const float u[4] = {u01(rnd.x), u01(rnd.y), u01(rnd.z), u01(rnd.w)};
                 const float4 ex = A.scene.exact[idx], m0 = A.scene.mat0[idx], m1 = A.scene.mat1[idx];
                 Ray out;

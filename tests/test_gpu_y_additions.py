@@ -153,3 +153,17 @@ def test_drop_in_executable_writes_the_reference_file(gpu_ctx, tmp_path):
     data2 = (tmp_path / "image_binary.ppm").read_bytes()
     got2 = np.frombuffer(data2[len(header):], np.uint8).reshape(H, W, 3)
     assert np.abs(got2.astype(int) - want.astype(int)).max() <= 1               # four fp32 partial sums instead of one: last-bit rounding only
+
+
+def test_image_sides_beyond_65535_are_refused(gpu_ctx):
+    """The render kernel keeps a pixel's column and row in one register (16 bits each): wider or taller images are
+    refused with RTK_ERR_TOO_LARGE before anything is allocated or launched."""
+    import torch
+    cam = rt.stock_camera(1.5)
+    dummy = torch.zeros(64 * 3, dtype=torch.float32, device="cuda:0")
+    for w, h in ((65536, 2), (2, 70000)):
+        p = rt.make_params(w, h, 1, 5, 0, 0.001, 0, 1, 8, 8, 0, 0)
+        with pytest.raises(rt.RtkError, match="65535"):
+            gpu_ctx.render_tiles_device(cam, p, dummy.data_ptr())
+    img, st = gpu_ctx.render(cam, 16, 8, 2, 5)                      # the context is still usable
+    assert img.shape == (8, 16, 3) and st["samples"] == 16 * 8 * 2
