@@ -71,8 +71,8 @@ typedef struct rtk_camera {
 
 /* Inputs of the pixel/sample loops, main.cpp:24-41 and 64-76. */
 typedef struct rtk_params {
-    int32_t width;        /* image_width  */
-    int32_t height;       /* image_height */
+    int32_t width;        /* image_width  (2 .. 65535) */
+    int32_t height;       /* image_height (2 .. 65535) */
     int32_t spp;          /* samples_per_pixel */
     int32_t max_depth;    /* max_depth */
     uint64_t seed;        /* key of the counter-based RNG that replaces MathUtils.hpp:15-25 */
