@@ -139,3 +139,44 @@ def test_errors(gpu_ctx):
     with pytest.raises(rt.RtkError, match="0 spheres"):
         ctx.set_scene(bad)
     ctx.close()
+
+
+def _tangent_rays(rng, scene, n, dist_lo, dist_hi, rel_eps, first=0):
+    """Rays from `dist` away aimed at the silhouette of a random sphere, +- rel_eps radii; unnormalised directions."""
+    k = rng.integers(first, len(scene["cx"]), n)
+    c = np.stack([scene["cx"][k], scene["cy"][k], scene["cz"][k]], 1).astype(np.float64)
+    r = np.abs(scene["radius"][k].astype(np.float64))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = np.exp(rng.uniform(np.log(dist_lo), np.log(dist_hi), n)) + r
+    o = c + u * dist[:, None]
+    a = rng.normal(size=(n, 3)); a += (a * u).sum(1, keepdims=True) * -u; a /= np.linalg.norm(a, axis=1, keepdims=True)
+    s = np.clip(r * (1 + rel_eps * rng.uniform(-1, 1, n)) / dist, 0, 0.999)
+    d = -u * np.sqrt(1 - s * s)[:, None] + a * s[:, None]
+    d *= np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (n, 1)))
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("lo,hi", [(0.01, 1), (1, 30), (30, 300), (300, 3000), (3000, 1e5), (1e5, 1e8)])
+def test_tangent_rays_at_every_distance(gpu_ctx, oracle_stock, stock_scene_golden, lo, hi):
+    """Rays that graze a sphere's silhouette from 0.01 to 1e8 units away: the filter's margin (the matrix pipe's own fp32
+    accumulation of cancelling f16 part products, which the CPU build only bounds) must keep every sphere the reference's
+    rounding still hits — beyond a few hundred units that is spheres the ray misses by far.  Bit-exact against the oracle."""
+    rng = np.random.default_rng(int(lo * 100) + 7)
+    rays = np.concatenate([_tangent_rays(rng, stock_scene_golden, 6000, lo, hi, eps, first=1) for eps in (0.0, 1e-6, 1e-3, 0.3)])
+    check(gpu_ctx.intersect(rays), *oracle_stock.intersect(rays))
+
+
+def test_mixed_radii_scene_far_from_the_origin():
+    """General words (K = 32, two chained MFMAs) of a scene 3000 units from the origin: the tiles' scale follows the extent of
+    the centres, so the margin is at its widest."""
+    rng = np.random.default_rng(29)
+    s = _odd_scene(rng, 300)
+    s["cx"] += np.float32(3000.0); s["cy"] -= np.float32(200.0); s["cz"] += np.float32(1500.0)
+    o = po.Oracle(); o.set_scene(s)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    m = 20000
+    org = rng.uniform(-12, 12, (m, 3)) + np.array([3000.0, -200.0, 1500.0])
+    rays = np.concatenate([np.concatenate([org, rng.normal(size=(m, 3))], 1).astype(np.float32),
+                           _tangent_rays(rng, s, 8000, 0.5, 3000, 1e-5)])
+    check(ctx.intersect(rays), *o.intersect(rays))
+    ctx.close()
