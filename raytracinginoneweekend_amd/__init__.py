@@ -183,6 +183,32 @@ def stock_scene() -> dict:
     return scaled_scene()
 
 
+def mixed_radii_scene(n: int = 200, seed: int = 1, extent: float = 8.0) -> dict:
+    """A user scene (tests, tools): the ground sphere plus n - 1 spheres of varied radius resting on it, materials mixed.
+    No two small spheres share (cy, radius), so the matrix-pipe layout builds GENERAL words (and a few class words when n
+    is large): the loop the stock scene never enters."""
+    rng = np.random.default_rng(seed)
+    m = n - 1
+    r = rng.uniform(0.15, 0.6, m).astype(np.float32)
+    s = {k: np.zeros(n, np.float32) for k in SCENE_FIELDS[:10]}
+    s["mat_type"] = np.ones(n, np.int32)
+    s["cx"][1:] = rng.uniform(-extent, extent, m); s["cz"][1:] = rng.uniform(-extent, extent, m)
+    s["cy"][1:] = r; s["radius"][1:] = r
+    s["cy"][0] = -1000.0; s["radius"][0] = 1000.0
+    for k in ("mat_r", "mat_g", "mat_b"):
+        s[k][:] = rng.uniform(0.2, 0.95, n)
+    kind = rng.uniform(size=n)
+    s["mat_type"][kind > 0.6] = 2; s["mat_type"][kind > 0.85] = 3
+    s["mat_type"][0] = 1
+    s["roughness"][:] = np.where(s["mat_type"] == 2, rng.uniform(0, 0.5, n), 1.0)
+    s["metallic"][:] = np.where(s["mat_type"] == 2, 1.0, 0.0)
+    s["ior"][:] = np.where(s["mat_type"] == 3, 1.5, 0.0)
+    glass = s["mat_type"] == 3
+    for k in ("mat_r", "mat_g", "mat_b"):
+        s[k][glass] = 1.0
+    return s
+
+
 def camera(look_from, look_at, vup, vfov, aspect, aperture, focus) -> np.ndarray:
     out = np.zeros(22, np.float32)
     host_lib().rtiow_host_camera(np.asarray(look_from, np.float32), np.asarray(look_at, np.float32),

@@ -248,7 +248,11 @@ struct Intersector {
             uint32_t nz = 0;
             auto keep = [&](int w, uint32_t m) {          // the store is unconditional: nearly every word has a candidate on some lane
                 masks[w * kWave + lane] = m;
+#ifdef RTK_EXP_BRANCHFREE_BITMAP
+                nz |= static_cast<uint32_t>(m != 0) << (31 - w);          // experiment builds only (tools/asm_variant.py, tools/hazard_hunt/): the form whose frames differed
+#else
                 if (m != 0) nz |= 0x80000000u >> w;
+#endif
             };
             const bool has_class = (fb.kinds & 1) != 0, has_general = (fb.kinds & 2) != 0;       // wave-uniform
             // ---- the ray's side of the dot product ----

@@ -1,11 +1,17 @@
-"""tools/determinism_check.py <frames> — renders the same frame <frames> times with the library named by RTK_LIB (or the
-in-tree one) and reports how many distinct images came out (the image is defined by pixel, sample and seed alone: one)."""
+"""tools/determinism_check.py <frames> [--scene stock|mixed] [--grid] — renders the same 1200x800x60 frame <frames> times
+with the library named by RTK_LIB (or the in-tree one) and reports how many distinct images came out (the image is
+defined by pixel, sample and seed alone: one).  --scene mixed: 200 spheres of varied radius (general words, the loop the
+stock scene never enters).  --grid: one more frame through the uniform-grid kernel (no matrix instructions, another
+code path to the same closest hits): it must equal the list walk's image bit for bit, which is what tells a
+deterministically WRONG list walk from a right one."""
 import hashlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracinginoneweekend_amd as rt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+scene = sys.argv[sys.argv.index("--scene") + 1] if "--scene" in sys.argv else "stock"
 ctx = rt.Context(0)
-ctx.set_scene(rt.stock_scene())
+ctx.set_scene(rt.stock_scene() if scene == "stock" else rt.mixed_radii_scene(200))
+print("scene", scene, ctx.scene_layout(), flush=True)
 W, H, spp = 1200, 800, 60
 cam = rt.stock_camera(W / H)
 seen = {}
@@ -14,5 +20,14 @@ for i in range(n):
     h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
     seen[h] = seen.get(h, 0) + 1
     print(i, h, st["rays"], st["exact_tests"], st.get("samples"), st.get("lane_slots"), flush=True)
-print(os.environ.get("RTK_LIB", "in-tree"), "distinct images:", len(seen))
-sys.exit(0 if len(seen) == 1 else 1)
+ok = len(seen) == 1
+if "--grid" in sys.argv:
+    assert ctx.set_accel(rt.ACCEL_GRID) == rt.ACCEL_GRID
+    img, st = ctx.render(cam, W, H, spp, 50, seed=11)
+    h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
+    print("grid", h, st["rays"], flush=True)
+    same = h in seen
+    print("uniform-grid frame", "EQUALS" if same else "DIFFERS FROM", "the list walk's")
+    ok = ok and same
+print(os.environ.get("RTK_LIB", "in-tree"), "scene", scene, "distinct images:", len(seen))
+sys.exit(0 if ok else 1)
