@@ -15,10 +15,9 @@ HOST_CAPI = os.path.join(HERE, "librtiow_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact intersection stage and the shading arithmetic must round every fp32
 # operation separately, as the reference build does (rtk_device.hpp header comment).
-# -amdgpu-mfma-vgpr-form: the matrix instructions of the filter write ordinary VGPRs (their results feed vector FMAs at
-# once; with accumulation registers every result would cost a v_accvgpr_read first).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
-             "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# No -mllvm options: the filter's matrix instructions are asm statements that name ordinary VGPRs as their results
+# (rtk_intersect.hpp mfma_pair), so the experimental -amdgpu-mfma-vgpr-form of round 2 is no longer needed.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target: str, sources) -> bool:
@@ -37,6 +36,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     return LIB
+
+
+def build_known_bad(force: bool = False, verbose: bool = False) -> str:
+    """variants/librtk_known_bad.so — TEST INFRASTRUCTURE, never loaded by the product: the shipped kernel source with one
+    scalar move between the two MFMAs of a filter word (profiles/r03_hazard_notes.md), the form that computed wrong
+    candidate words on MI355X.  tests/test_gpu_render.py::test_known_bad_loop_form_is_caught renders with it and expects
+    the parity checks to fail; tests/test_cabi.py expects the code-object lint to flag it."""
+    out = os.path.join(HERE, "variants", "librtk_known_bad.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rtk.h")]
+    if force or _stale(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = [HIPCC, *HIP_FLAGS, "-DRTK_EXP_SCALAR_BETWEEN_MFMAS=1", "-shared", "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "rtk.hip"), "-o", out]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return out
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
@@ -74,6 +89,7 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     build_lib(force, verbose)
     build_host_capi(force, verbose)
     build_host(force, verbose)
+    build_known_bad(force, verbose)
 
 
 if __name__ == "__main__":

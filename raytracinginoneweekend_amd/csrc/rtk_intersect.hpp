@@ -22,23 +22,44 @@ namespace rtk {
 // Stage 3 (exact): each lane walks its own candidates with the reference's arithmetic and range tests
 // against its running `closest`; ascending order reproduces the reference's tie rule (a later
 // sphere with root == closest replaces, Sphere3.hpp:43 `t_max < root`) and its NaN behaviour.
-// Keeps the machine scheduler from moving instructions across this point (it otherwise sinks prefetches to their use).
-// A 32x32 MFMA's result registers must not overlap its A or B operand (the matrix pipe reads them over several passes).
-// The compiler knows that for results in AGPRs; in the VGPR form this library is built with (-amdgpu-mfma-vgpr-form) it
-// has been seen to give the result tile the registers of an operand whose last use the MFMA is — frames then differed
-// from run to run (tools/determinism_check.py; tests/test_cabi.py checks the built code object for such overlaps).  This
-// empty statement reads the operands AFTER the results exist, so their registers cannot be reused for the results.
-#ifdef RTK_HOST_EMULATION
-#define RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, x, y) ((void)0)
+// ---- how the matrix instructions of the filter are issued (profiles/r03_hazard_notes.md) -------------
+// Two v_mfma_f32_32x32x16_f16 of one wave that NAME THE SAME A REGISTERS must follow each other directly.  With a
+// scalar-ALU instruction (s_cmp, s_mov, ...) or a waiting s_waitcnt issued between them, the render kernel computed a few
+// hundred wrong candidate words per 1.7e8 rays once three or more waves shared a SIMD: frames differed from run to run
+// and from the uniform-grid kernel's.  Found by editing single instructions of the built code object
+// (tools/asm_variant.py, tools/hazard_hunt/): the shipped loop with one s_mov_b32 s, s moved between its two MFMAs
+// fails, with s_nop or a vector move in the same place it is exact, and with the second MFMA reading a COPY of the A
+// fragment in other registers it is exact again.  Which of the loop's instructions the compiler's scheduler puts
+// between two builtin MFMAs is not under the source's control (three source forms of rounds 2 scheduled the loop
+// compare there), so the MFMAs of one word are ONE asm statement: nothing can be scheduled between them, the result
+// tiles are early-clobber outputs (a 32x32 result must not overlap its A or B operand: the matrix pipe reads them over
+// several passes) and the wait states an 8-pass matrix result needs before any reader (12) are part of the statement —
+// the compiler's hazard recogniser does not look inside asm.  tests/test_cabi.py checks the built code object: every
+// v_mfma is directly followed by another v_mfma or by the statement's s_nop.
+// RTK_EXP_SCALAR_BETWEEN_MFMAS (experiment builds only, tools/build_variants.py): the known-bad form, for
+// tests/test_gpu_render.py::test_known_bad_loop_form_is_caught.
+#ifndef RTK_HOST_EMULATION
+typedef _Float16 rtk_f16x8 __attribute__((ext_vector_type(8)));
+typedef float rtk_f32x16 __attribute__((ext_vector_type(16)));
+#ifdef RTK_EXP_SCALAR_BETWEEN_MFMAS
+#define RTK_BETWEEN_MFMAS "s_mov_b32 s32, s32\n\t"
 #else
-#define RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, x, y) asm volatile("" : "+v"(d0), "+v"(d1) : "v"(x), "v"(y))
+#define RTK_BETWEEN_MFMAS ""
 #endif
-#ifdef RTK_HOST_EMULATION
-#define RTK_SCHED_BARRIER() ((void)0)
-#else
-#define RTK_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// d0 = A x B0, d1 = A x B1: one tile of 32 spheres against the two groups of 32 rays (K = 16)
+__device__ __forceinline__ void mfma_pair(rtk_f32x16& d0, rtk_f32x16& d1, rtk_f16x8 a, rtk_f16x8 b0, rtk_f16x8 b1) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\t" RTK_BETWEEN_MFMAS "v_mfma_f32_32x32x16_f16 %1, %2, %4, 0\n\ts_nop 11"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(a), "v"(b0), "v"(b1));
+}
+// the same for K = 32 (general words): two fragment sets chained through the C operand
+__device__ __forceinline__ void mfma_quad(rtk_f32x16& d0, rtk_f32x16& d1, rtk_f16x8 a0, rtk_f16x8 a1, rtk_f16x8 b00, rtk_f16x8 b01, rtk_f16x8 b10, rtk_f16x8 b11) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_f16 %1, %2, %5, 0\n\t"
+                 "v_mfma_f32_32x32x16_f16 %0, %3, %6, %0\n\tv_mfma_f32_32x32x16_f16 %1, %3, %7, %1\n\ts_nop 11"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(a0), "v"(a1), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+}
 #endif
-
 // Scenes beyond kMaxLdsSpheres stream the sphere list through a wave-private LDS chunk (one coalesced global load per
 // 64 spheres) instead of reading every sphere with a broadcast global load (measured on the 10k-sphere scene of
 // BASELINE.json configs[3]: 1.56x the broadcast-load walk, profiles/r02_config4.md).
@@ -248,11 +269,7 @@ struct Intersector {
             uint32_t nz = 0;
             auto keep = [&](int w, uint32_t m) {          // the store is unconditional: nearly every word has a candidate on some lane
                 masks[w * kWave + lane] = m;
-#ifdef RTK_EXP_BRANCHFREE_BITMAP
-                nz |= static_cast<uint32_t>(m != 0) << (31 - w);          // experiment builds only (tools/asm_variant.py, tools/hazard_hunt/): the form whose frames differed
-#else
                 if (m != 0) nz |= 0x80000000u >> w;
-#endif
             };
             const bool has_class = (fb.kinds & 1) != 0, has_general = (fb.kinds & 2) != 0;       // wave-uniform
             // ---- the ray's side of the dot product ----
@@ -377,8 +394,8 @@ struct Intersector {
             // B fragments: lane l supplies B[k = 8 (l >> 5) + j][column l & 31].  For the first 32 rays lanes 0..31 give
             // their own k 0..7 and lanes 32..63 the k 8..15 of the ray of lane l - 32; for the second 32 rays the other
             // way round: exactly what v_permlane32_swap(lo, hi) yields.  The constants travel the same way.
-            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-            typedef float f32x16 __attribute__((ext_vector_type(16)));
+            typedef rtk_f16x8 f16x8;
+            typedef rtk_f32x16 f32x16;
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             auto fragments = [](const uint16_t* v, f16x8 out[2]) {          // 16 terms -> the B operands of the two ray groups
@@ -398,12 +415,6 @@ struct Intersector {
                 kcg[0] = __uint_as_float(a1[0]); kcg[1] = __uint_as_float(a1[1]);
                 kgg[0] = __uint_as_float(a2[0]); kgg[1] = __uint_as_float(a2[1]);
             }
-            // Nothing this wave sent to the vector memory path earlier (the accumulator atomics of a retired unit, material
-            // gathers) may still be queued when the matrix instructions start: such an instruction reads its address
-            // registers late, and the compiler is free to make those registers part of an MFMA's result tile (seen on the
-            // GPU: images differed from run to run; tools/determinism_check.py).
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const float nbig = -0x1p48f;
             // 16 results of a lane -> 16 mask bits, first sphere in the highest bit: registers 2 m hold spheres 16 hf + m,
             // registers 2 m + 1 spheres 16 hf + 8 + m; one fp32 accumulator (16 bits: exact)
@@ -431,9 +442,8 @@ struct Intersector {
                     const float4 av = filt[wi * kWave + lane];
                     f16x8 a0;
                     __builtin_memcpy(&a0, &av, 16);
-                    f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
-                    f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
-                    RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a0, a0);
+                    f32x16 d0, d1;
+                    mfma_pair(d0, d1, a0, bc[0], bc[1]);
                     const uint32_t m = join(bits16(d0, kcg[0]), bits16(d1, kcg[1]));
                     RTK_STAT(lane, class_words);
                     RTK_STAT(lane, filter_words);
@@ -454,19 +464,15 @@ struct Intersector {
                     f32x16 d0, d1;
                     float k0, k1;
                     if (cls) {
-                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[0], zero, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bc[1], zero, 0, 0, 0);
+                        mfma_pair(d0, d1, a0, bc[0], bc[1]);
                         k0 = kcg[0]; k1 = kcg[1];
                     } else {
                         const float4 av1 = tile[kWave + lane];
                         f16x8 a1;
                         __builtin_memcpy(&a1, &av1, 16);
-                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[0], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[0], zero, 0, 0, 0), 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bg1[1], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bg0[1], zero, 0, 0, 0), 0, 0, 0);
+                        mfma_quad(d0, d1, a0, a1, bg0[0], bg0[1], bg1[0], bg1[1]);
                         k0 = kgg[0]; k1 = kgg[1];
-                        RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a1, a1);
                     }
-                    RTK_MFMA_OPERANDS_OUTLIVE(d0, d1, a0, a0);
                     const uint32_t m = join(bits16(d0, k0), bits16(d1, k1));
                     if (cls) RTK_STAT(lane, class_words);
                     RTK_STAT(lane, filter_words);

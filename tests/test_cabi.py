@@ -102,20 +102,54 @@ def test_rccl_library_offers_what_rtk_multi_opens_on_demand():
         assert hasattr(l, name), name
 
 
-def test_no_mfma_result_overlaps_its_operands(tmp_path):
-    """A 32x32 MFMA's result registers must not overlap its A or B operand, and its C operand only exactly (the matrix
-    pipe reads the operands over several passes).  Built with -amdgpu-mfma-vgpr-form the compiler has violated this (frames
-    differed from run to run on the GPU); rtk_intersect.hpp keeps the operands live past the results, and this test reads the
-    shipped code object to see that it worked."""
-    import re, subprocess
+def _disassembly(tmp_path, lib=None):
+    """Disassembly of the gfx950 code object inside the built library (skips where the ROCm LLVM tools are missing)."""
+    import subprocess
     llvm = "/opt/rocm/lib/llvm/bin"
-    lib = os.path.join(ROOT, "raytracinginoneweekend_amd", "librtk.so")
+    lib = lib or os.path.join(ROOT, "raytracinginoneweekend_amd", "librtk.so")
     if not (os.path.exists(lib) and os.path.exists(f"{llvm}/llvm-objdump")):
         pytest.skip("needs the built library and the ROCm LLVM tools")
     fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "rtk.co")
     subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
     subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-    txt = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    return subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+
+
+def _mfma_followers(txt):
+    """[(mfma line, mnemonic and operands of the instruction after it)] for every v_mfma in a disassembly."""
+    import re
+    ins = [m.group(1).strip() for m in (re.match(r"\s+([a-z_0-9]+\s[^/]*|[a-z_0-9]+)\s*//", ln) for ln in txt.splitlines()) if m]
+    return [(a, b) for a, b in zip(ins, ins[1:] + [""]) if a.startswith("v_mfma")]
+
+
+def test_matrix_instructions_are_issued_back_to_back(tmp_path):
+    """profiles/r03_hazard_notes.md: two MFMAs of a wave that name the same A registers with a scalar-ALU instruction (or a
+    waiting s_waitcnt) between them gave wrong candidate words in the render kernel (found by moving single instructions
+    of the built code object: tools/asm_variant.py).  The filter's MFMAs are asm statements now, so the compiler cannot
+    schedule anything between them; this reads the SHIPPED code object: every v_mfma is directly followed by another
+    v_mfma or by the statement's own s_nop 11 (the wait states an 8-pass result needs)."""
+    pairs = _mfma_followers(_disassembly(tmp_path))
+    assert len(pairs) >= 12          # render and intersect kernel: class-only loop (2), mixed loop (2 + 4)
+    for mfma, nxt in pairs:
+        assert nxt.startswith("v_mfma") or nxt.replace(" ", "") == "s_nop11", (mfma, nxt)
+
+
+def test_the_known_bad_build_violates_the_back_to_back_rule(tmp_path):
+    """The lint above must be able to fail: the experiment build with a scalar move between the MFMAs (the form
+    tests/test_gpu_render.py::test_known_bad_loop_form_is_caught renders with) is caught by it."""
+    bad = os.path.join(ROOT, "raytracinginoneweekend_amd", "variants", "librtk_known_bad.so")
+    if not os.path.exists(bad):
+        pytest.skip("variants/librtk_known_bad.so not built (__graft_entry__.build() makes it)")
+    pairs = _mfma_followers(_disassembly(tmp_path, bad))
+    assert any(nxt.startswith("s_mov_b32") for _, nxt in pairs)
+
+
+def test_no_mfma_result_overlaps_its_operands(tmp_path):
+    """A 32x32 MFMA's result registers must not overlap its A or B operand, and its C operand only exactly (the matrix
+    pipe reads the operands over several passes).  The result tiles are early-clobber outputs of the asm statements in
+    rtk_intersect.hpp (mfma_pair, mfma_quad); this test reads the shipped code object to see that it holds."""
+    import re
+    txt = _disassembly(tmp_path)
 
     def regs(op):
         m = re.fullmatch(r"([av])\[(\d+):(\d+)\]", op)

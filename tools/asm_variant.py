@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raytracinginoneweekend_amd", "csrc")
 OUT = os.path.join(ROOT, "raytracinginoneweekend_amd", "variants")
 LLVM = "/opt/rocm/lib/llvm/bin"
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I", os.path.join(ROOT, "include")]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include")]
 
 
 def run(cmd):

@@ -9,7 +9,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raytracinginoneweekend_amd", "csrc")
 OUT = os.path.join(ROOT, "raytracinginoneweekend_amd", "variants")
-BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-shared", "-I", os.path.join(ROOT, "include")]
+BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include")]
 os.makedirs(OUT, exist_ok=True)
 for spec in sys.argv[1:] or ["ship"]:
     name, _, flags = spec.partition("=")
