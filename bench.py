@@ -43,12 +43,15 @@ from raytracinginoneweekend_amd.distributed import ShardedRenderer  # noqa: E402
 W, H, SPP, DEPTH = 1200, 800, 500, 50
 FLOP_PER_TEST = 17          # oc 3, half_b 5, |oc|^2 5, -r^2 1, disc 3
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
-# Scenes whose filter runs on the matrix pipe: a word of 32 spheres x 64 rays = 2048 tests costs a SIMD at least 2 x 32 cycles of
-# v_mfma_f32_32x32x16_f16 plus 2 fp32 FMAs per test and lane = 128 cycles of VALU issue, and the two do not overlap on one SIMD
-# (tools/mfma_valu_overlap.hip): 2048 x 17 algorithmic flop / 192 cycles x 1024 SIMDs x 2.4 GHz.  The fp32 vector peak alone is no
-# upper bound of that mapping (most of a test's arithmetic is f16 products on the matrix pipe).
-ISSUE_BOUND_PEAK_TFLOPS = 2048 * 17 / 192 * 1024 * 2.4e9 / 1e12
-KERNEL_TAG = "r02-e (dot-product filter: squared distance minus r^2 of 32 spheres x 32 rays as one f16 MFMA from two-part splits of the centre's monomials and the ray's coefficients, threshold and bit accumulation in 2 fp32 FMAs per test; candidate mask words in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
+# Scenes whose filter runs on the matrix pipe: a word of 32 spheres x 64 rays = 2048 tests costs a SIMD 2 x 32 cycles of
+# v_mfma_f32_32x32x16_f16 AND 2 fp32 FMAs per test and lane = 128 cycles of VALU issue.  The two pipes of a SIMD run side by
+# side (SQ_VALU_MFMA_COEXEC_CYCLES of this kernel: 0.67 of its matrix cycles have a vector instruction executing too,
+# profiles/r03_summary.md; MI355X_MICROARCH.md: separate pipes), so the mapping's bound is the LONGER of the two, the 128 VALU
+# cycles: 2048 x 17 algorithmic flop / 128 cycles x 1024 SIMDs x 2.4 GHz = 668.5 TFLOP/s.  (Round 2 priced the mapping at
+# 64 + 128 = 192 cycles, 445.6 TFLOP/s, on the strength of a microbenchmark that the counter contradicts.)  The fp32 vector peak
+# alone is no upper bound of the mapping: most of a test's arithmetic is f16 products on the matrix pipe.
+ISSUE_BOUND_PEAK_TFLOPS = 2048 * 17 / 128 * 1024 * 2.4e9 / 1e12
+KERNEL_TAG = "r03-a (dot-product filter: squared distance minus r^2 of 32 spheres x 32 rays as one f16 MFMA from two-part splits of the centre's monomials and the ray's coefficients, the MFMAs of a word issued back to back as one asm statement, threshold and bit accumulation in 2 fp32 FMAs per test; candidate mask words in LDS; per-sample fixed-point sums, run schedule sized per rank)"   # bump when the kernel changes
 
 
 # BASELINE.json configs[0] — the reference's own CPU-runnable case: `400 225 10 50`.  The reference is deterministic
@@ -93,6 +96,29 @@ def cpu_baseline():
             "samples_per_s": W1 * H1 * spp1 / secs}
 
 
+def workload_labels(args, n_spheres):
+    """metric / workload strings and whether this run is the headline workload (BASELINE.json configs[1] exactly: stock scene,
+    list walk, 1200 x 800, 500 spp, depth 50).  Any other size or scene names its own BASELINE config (or says it has none)."""
+    size = (args.width, args.height, args.spp, args.depth)
+    stock = args.scene_k <= 0 and not args.glass and args.mixed <= 0
+    headline = stock and args.accel == "list" and size == (W, H, SPP, DEPTH)
+    walk = "uniform grid (bit-identical image, fewer sphere tests; not the roofline's algorithm)" if args.accel == "grid" else "list walk"
+    dims = f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}"
+    if args.mixed > 0:
+        cfg, scene = "no BASELINE config (user scene)", f"{n_spheres} spheres of varied radius (general words)"
+    elif args.glass:
+        cfg, scene = "BASELINE.json configs[4]", f"glass/metal-heavy scene ({n_spheres} spheres, material thresholds 0.1/0.5)"
+    elif args.scene_k > 0:
+        cfg, scene = "BASELINE.json configs[3] (scaled list)", f"{n_spheres} spheres on [-{args.scene_k},{args.scene_k})^2"
+    else:
+        scene = f"book-1 final random-spheres scene ({n_spheres} spheres, libstdc++ default-seeded)"
+        cfg = ("BASELINE.json configs[1]" if size == (W, H, SPP, DEPTH) else "BASELINE.json configs[2] (on %d GPU(s))" % args.gpus if size == (3840, 2160, 1000, 50) else
+               "BASELINE.json configs[0] (the reference's CPU case, here on the GPU)" if size == (400, 225, 10, 50) else "no BASELINE config (stock scene at another size)")
+    metric = ("Mrays/s (whole node), final scene 1200x800 500spp" if headline else
+              f"Mrays/s (whole node), NOT the headline workload: {cfg}: {scene}, {dims}, {'uniform grid' if args.accel == 'grid' else 'list walk'}")
+    return {"headline": headline, "metric": metric, "workload": f"{cfg}: {scene}, {dims}, stock camera, closest hit by {walk}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +135,11 @@ def main():
                          "DESIGN.md §7; per-kernel event times then include the overlap)")
     ap.add_argument("--scene-k", type=int, default=0,
                     help="0: the stock 484-sphere scene (the metric's workload).  K > 0: BASELINE.json config 4, the same generator on a [-K,K)^2 grid (K=50: 10k spheres)")
+    ap.add_argument("--glass", action="store_true",
+                    help="BASELINE.json configs[4]: the stock generator with the material thresholds of main.cpp:130,133 moved from 0.8/0.95 to 0.1/0.5 "
+                         "(10 %% diffuse, 40 %% metal, 50 %% glass); use with --depth 100")
+    ap.add_argument("--mixed", type=int, default=0,
+                    help="N > 0: a user scene of N spheres of varied radius (general words of the matrix-pipe layout; not a BASELINE config)")
     ap.add_argument("--accel", choices=("list", "grid"), default="list",
                     help="list: the reference's list walk (the metric's path, roofline applies).  grid: uniform grid (SURVEY.md §8f-3), same image, reported separately")
     args = ap.parse_args()
@@ -124,7 +155,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     ctx = rt.Context(local_rank)
-    scene = rt.stock_scene() if args.scene_k <= 0 else rt.scaled_scene(k=args.scene_k)
+    if sum(bool(x) for x in (args.scene_k > 0, args.glass, args.mixed > 0)) > 1:
+        raise SystemExit("--scene-k, --glass and --mixed exclude each other")
+    scene = (rt.mixed_radii_scene(args.mixed) if args.mixed > 0 else rt.scaled_scene(diffuse_below=0.1, metal_below=0.5) if args.glass else
+             rt.stock_scene() if args.scene_k <= 0 else rt.scaled_scene(k=args.scene_k))
     ctx.set_scene(scene)
     if args.accel == "grid" and ctx.set_accel(rt.ACCEL_GRID) != rt.ACCEL_GRID:
         raise SystemExit("the grid was refused for this scene: " + rt.lib().rtk_last_error().decode())
@@ -203,9 +237,18 @@ def main():
                 traffic = tj.get("bytes_per_launch") if tj.get("kernel_tag") == KERNEL_TAG else None      # measured on configs[1] at one GPU: see below
             except Exception:
                 traffic = None
-        headline = args.scene_k <= 0 and args.accel == "list"
-        if not (headline and world == 1 and (args.width, args.height, args.spp) == (1200, 800, 500)):
+        wl = workload_labels(args, n_spheres)
+        headline = wl["headline"]
+        counters = {}
+        if not (headline and world == 1):
             traffic = None          # the counters were collected on configs[1] at one GPU only
+        elif os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("kernel_tag") == KERNEL_TAG:
+                    counters = {k: tj[k] for k in ("valu_issue_util", "mfma_busy", "mfma_valu_coexec", "source") if k in tj}
+            except Exception:
+                counters = {}
         lay = ctx.scene_layout()
         n_class = 32 * lay["class_words"]
         on_matrix_pipe = n_spheres <= 1024
@@ -213,16 +256,11 @@ def main():
         filt_valu = 2.0 if on_matrix_pipe else 8.0                                      # vector instructions per ray-sphere filter test
         alg_bytes = args.width * args.height * 3 * (8 + 4) / world                       # per launch: one u64 accumulator + one fp32 sum per channel
         out = {
-            "metric": "Mrays/s (whole node), final scene 1200x800 500spp" if headline else
-                      "Mrays/s (whole node), NOT the headline workload: %s, %s" % ("stock scene" if args.scene_k <= 0 else "config-4 scene k=%d (%d spheres)" % (args.scene_k, n_spheres),
-                                                                                  "uniform grid" if args.accel == "grid" else "list walk"),
+            "metric": wl["metric"],
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: book-1 final random-spheres scene (484 spheres, libstdc++ default-seeded), " if args.scene_k <= 0 else
-                                    f"BASELINE.json configs[3] (scaled list): {n_spheres} spheres on [-{args.scene_k},{args.scene_k})^2, ") +
-                                   f"{args.width}x{args.height}, {args.spp} spp, depth {args.depth}, stock camera, closest hit by " +
-                                   ("uniform grid (bit-identical image, fewer sphere tests; not the roofline's algorithm)" if args.accel == "grid" else "list walk"),
+            "config": {"workload": wl["workload"],
                        "sharding": f"8x8-pixel tiles interleaved over {world} rank(s), one all_gather of fp32 tile sums per frame",
                        "rays_per_sample": rays / samples, "samples_per_s": samples / elapsed_max, "frames_in_flight": args.frames_in_flight},
             "roofline": {"bound": "simd_issue (mfma f16 + valu fp32)" if on_matrix_pipe else "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -230,7 +268,8 @@ def main():
                          "traffic": traffic, "kernel": "render_kernel<true>" if n_spheres <= 1024 else "render_kernel<false>", "kernel_tag": KERNEL_TAG, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "flop_per_ray": FLOP_PER_TEST * n_spheres, "rays_per_launch": k_rays, "per_rank_kernel_ms": per_rank_ms,
                          "basis": "ALGORITHMIC flops (17 per ray-sphere test x spheres x rays, SURVEY.md §8d), not executed ones, " +
-                                  ("against the issue bound of the filter's mapping (per 2048 tests 64 cycles of MFMA + 128 of VALU per SIMD, which do not overlap: 445.6 TFLOP/s; "
+                                  ("against the issue bound of the filter's mapping (per 2048 tests 64 cycles of MFMA and 128 of VALU per SIMD, which run side by side — measured, "
+                                   "mfma_valu_coexec — so the bound is the 128: 668.5 TFLOP/s; round 2 divided by 445.6 = the two added; "
                                    "frac_of_fp32_vector_peak is the measure of rounds 1-2, no longer an upper bound): " if on_matrix_pipe else "against the fp32 VECTOR peak: ") +
                                   "the kernel runs a conservative "
                                   "filter per test (" + ("one dot product of split-f16 monomials and coefficients on the matrix pipe, 2 x v_mfma_f32_32x32x16_f16 per class word of 32 spheres x 64 rays, then 2 fp32 vector FMAs"
@@ -240,7 +279,10 @@ def main():
                          "filter_valu_per_test": filt_valu, "class_words": lay["class_words"], "lds_bytes_per_workgroup": lay["lds_bytes_per_workgroup"],
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "lane_utilisation": rays / max(1.0, lane_slots), "exact_tests_per_ray": exact / max(1.0, rays),
-                         "drain_frac_last_frame": drain_frac},
+                         "drain_frac_last_frame": drain_frac,
+                         # hardware counters of this kernel build on this workload (rocprofv3 --pmc, profiles/<round>_summary.md; replayed by
+                         # kernel tag, not collected in this run: counters need the profiler): fractions of the SIMDs' cycles
+                         "counters": counters or None},
         }
         if args.accel == "grid":
             # the 17-flop-per-test model prices the list walk; with a grid the useful figure is tests per ray

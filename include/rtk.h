@@ -144,9 +144,10 @@ int rtk_context_set_accel(rtk_context* ctx, int32_t mode);
 int rtk_accel_in_use(rtk_context* ctx);
 
 /* How the resident scene is laid out for the kernels (diagnostics for bench.py and the profile summaries; no counterpart
- * in the reference): out4 = { spheres, words of 32 consecutive spheres that share cy and radius and are filtered with
- * 7 instead of 8 vector instructions per test (every small sphere of random_scene(), main.cpp:124, qualifies),
- * 1 if the scene is LDS-resident, LDS bytes per workgroup of the render kernel }. */
+ * in the reference): out4 = { spheres, CLASS words (32 consecutive list entries whose filterable spheres share cy and
+ * radius — every small sphere of random_scene(), main.cpp:124, qualifies — so that their filter test is 15 terms of one
+ * dot product: two v_mfma_f32_32x32x16_f16 per word of 32 spheres x 64 rays instead of four for a general word),
+ * 1 if the scene is LDS-resident (at most 1024 spheres), LDS bytes per workgroup of the render kernel }. */
 int rtk_scene_layout(rtk_context* ctx, int32_t* out4);
 
 /* Upload the flattened world.  Replaces the traversal state HittableList::hit walks

@@ -86,7 +86,7 @@ def test_headline_line(bench, monkeypatch, capsys):
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None and "workload" in j["config"]
     r = j["roofline"]
     assert r["bound"].startswith("simd_issue") and r["unit"] == "TFLOP/s" and r["peak"] == bench.ISSUE_BOUND_PEAK_TFLOPS
-    assert abs(r["peak"] - 445.6) < 0.1 and r["fp32_vector_peak"] == bench.FP32_VECTOR_PEAK_TFLOPS
+    assert abs(r["peak"] - 668.5) < 0.1 and r["fp32_vector_peak"] == bench.FP32_VECTOR_PEAK_TFLOPS          # the VALU side of the mapping: the pipes co-execute
     assert abs(r["frac_of_fp32_vector_peak"] - r["achieved"] / 157.3) < 1e-12
     # 1000 rays per 2 ms launch x 484 spheres x 17 flop
     assert r["rays_per_launch"] == 1000 and abs(r["kernel_ms"] - 2.0) < 1e-9
@@ -106,3 +106,24 @@ def test_grid_and_config4_are_labelled_as_not_the_headline(bench, monkeypatch, c
     assert "NOT the headline workload" in j["metric"] and "uniform grid" in j["config"]["workload"]
     assert j["roofline"]["frac"] is None and j["roofline"]["kernel"] == "render_kernel<false, true>"
     assert "cpu_baseline" not in j
+
+
+@pytest.mark.parametrize("argv,cfg,headline", [
+    ((), "configs[1]", True),
+    (("--width", "3840", "--height", "2160", "--spp", "1000"), "configs[2]", False),
+    (("--width", "400", "--height", "225", "--spp", "10"), "configs[0]", False),
+    (("--spp", "60"), "no BASELINE config", False),
+    (("--depth", "100"), "no BASELINE config", False),
+    (("--glass", "--depth", "100"), "configs[4]", False),
+    (("--scene-k", "3"), "configs[3]", False),
+    (("--mixed", "200"), "no BASELINE config (user scene)", False),
+])
+def test_every_size_and_scene_names_its_own_config(bench, monkeypatch, capsys, argv, cfg, headline):
+    """Only configs[1] exactly (stock scene, list walk, 1200x800, 500 spp, depth 50) carries the headline metric string;
+    everything else says which BASELINE config it is (round 2 labelled a 3840x2160x1000 run as the headline)."""
+    j = run(bench, monkeypatch, capsys, "--steps", "2", "--warmup", "0", *argv)
+    assert (j["metric"] == "Mrays/s (whole node), final scene 1200x800 500spp") == headline
+    assert cfg in j["config"]["workload"] and (headline or cfg in j["metric"])
+    assert j["roofline"].get("traffic") is None or headline          # counters are replayed for the headline workload only
+    w = [a for a in argv if a.isdigit()]
+    assert all(x in j["config"]["workload"] for x in w if len(x) >= 3)

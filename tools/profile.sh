@@ -19,7 +19,7 @@ for PMC in \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE GRBM_COUNT" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
-  "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+  "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES"
 do
   i=$((i+1))
   echo "== pmc pass $i: $PMC"

@@ -17,7 +17,8 @@ for world in worlds:
     nlt = rt.lib().rtk_local_tile_count(W, H, 8, 8, 0, world)
     out = torch.zeros((nlt, 64, 3), dtype=torch.float32, device="cuda:0")
     for run_len in (0, -256, -64, -32, 1):
-        n_runs = rt.lib().rtk_run_schedule(SPP, W, H, run_len, None, 0)
+        # the partition is sized for THIS rank's pixels (render_tiles_impl: n_local_px = local tiles x 64), not for the full frame
+        n_runs = rt.lib().rtk_run_schedule(SPP, 64, int(nlt), run_len, None, 0)
         ms = []
         for rep in range(3):
             p = rt.make_params(W, H, SPP, DEPTH, rep, 0.001, 0, world, 8, 8, run_len, 0)

@@ -77,15 +77,22 @@ frac_trace_vec = alg_flop / (avg_ms * 1e-3) / 1e12 / PEAK_TF
 fetch_b = pmc.get("FETCH_SIZE", 0.0) * 1024 * 2
 write_b = pmc.get("WRITE_SIZE", 0.0) * 1024
 have_traffic = "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc
-if have_traffic:
-    json.dump({"tag": tag, "kernel_tag": roof.get("kernel_tag"), "bytes_per_launch": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
-               "algorithmic_bytes": roof.get("algorithmic_bytes_per_launch"),
-               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported "
-                       "(calibrated there for dword float atomics; this kernel's atomics are 8-byte integer adds); per render_kernel launch"},
-              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 cyc = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8          # summed over 8 XCDs
 clock_ghz = cyc / (avg_ms * 1e-3) / 1e9 if cyc else float("nan")
 valu = pmc.get("SQ_INSTS_VALU", 0.0)
+mfma_busy_c = pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+coexec_c = pmc.get("SQ_VALU_MFMA_COEXEC_CYCLES")
+valu_util = valu / N_SIMD * 2 / cyc if cyc else None
+mfma_busy = mfma_busy_c / N_SIMD / cyc if cyc else None
+coexec = coexec_c / N_SIMD / cyc if (cyc and coexec_c is not None) else None
+if have_traffic:
+    json.dump({"tag": tag, "kernel_tag": roof.get("kernel_tag"), "bytes_per_launch": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
+               "algorithmic_bytes": roof.get("algorithmic_bytes_per_launch"),
+               "valu_issue_util": valu_util, "mfma_busy": mfma_busy, "mfma_valu_coexec": coexec,
+               "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc of bench.py's headline workload, one GPU; fractions of SIMD cycles)",
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported "
+                       "(calibrated there for dword float atomics; this kernel's atomics are 8-byte integer adds); per render_kernel launch"},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 fma, add, mul, trans = (pmc.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32"))
 exec_frac = (2 * fma + add + mul) * 64 / (avg_ms * 1e-3) / (PEAK_TF * 1e12)
 wc = max(1.0, pmc.get("SQ_WAVE_CYCLES", 1))
@@ -112,7 +119,8 @@ lines = [
     f"| VALU issue utilisation | {valu / N_SIMD * 2 / cyc if cyc else float('nan'):.3f} (2 cycles per wave64 VALU instruction per SIMD) | SQ_INSTS_VALU x 2 / (SIMDs x cycles) |",
     f"| matrix pipe | busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / N_SIMD / cyc if cyc else float('nan'):.3f} of SIMD cycles = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 / wave_passes:.1f} MFMAs of 32 cycles per wavefront pass; "
     f"executed f16 matrix flops {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 1e12:.0f} TF/s = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 2.5e15:.3f} of the 2.5 PF dense f16 peak; "
-    f"VALU + MFMA together occupy {(valu * 2 + g('SQ_VALU_MFMA_BUSY_CYCLES')) / N_SIMD / cyc if cyc else float('nan'):.3f} of the SIMDs' issue cycles (they do not overlap) | SQ_VALU_MFMA_BUSY_CYCLES |",
+    + (f"a vector instruction executes during {coexec_c / max(1.0, mfma_busy_c):.2f} of the matrix cycles (co-execution {coexec:.3f} of SIMD cycles): the two pipes run side by side, "
+       f"VALU or MFMA busy {valu_util + mfma_busy - coexec:.3f} of the SIMD cycles" if coexec is not None else "SQ_VALU_MFMA_COEXEC_CYCLES not collected") + " | SQ_VALU_MFMA_BUSY_CYCLES, SQ_VALU_MFMA_COEXEC_CYCLES |",
     f"| FP32 FMA / ADD / MUL / transcendental wave-instructions | {fma:.3e} / {add:.3e} / {mul:.3e} / {trans:.3e} | SQ_INSTS_VALU_* |",
     f"| EXECUTED fp32 flops (2 per FMA, 1 per ADD/MUL, x 64 lanes) as a fraction of the {PEAK_TF} TF peak | **{exec_frac:.3f}** (algorithmic flops against the same peak: {frac_trace_vec:.3f}) | counters / duration |",
     f"| SALU / LDS / SMEM / VMEM wave-instructions | {g('SQ_INSTS_SALU'):.3e} / {g('SQ_INSTS_LDS'):.3e} / {g('SQ_INSTS_SMEM'):.3e} / {g('SQ_INSTS_VMEM'):.3e} | SQ_INSTS_* |",
