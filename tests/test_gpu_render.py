@@ -272,6 +272,38 @@ def test_glass_heavy_config5_runs_and_matches_oracle_statistics():
     ctx.close()
 
 
+def test_glass_heavy_config4_image_gate_and_lane_utilisation():
+    """BASELINE.json configs[4] (Material.cpp:26-48 on half of the spheres, metal on 40 %, depth 100) to the bar of configs[1]:
+    the 500-spp GPU frame against the hash-pinned oracle's 2000-spp frame of the SAME scene arrays (tests/golden/
+    image_glass_120x80_2000spp.npz, tools/make_golden.py --glass): PSNR >= 40 dB on the write_color_binary bytes, i.e. 8-bit
+    RMSE <= 2.55; mean radiance within 0.5 %; rays per sample within 1 % (3.27: the glass paths are longer).  Then the
+    full-width frame: the lanes of the persistent waves stay busy (>= 0.9 of the lane slots trace a ray), which is what
+    decides against wavefront compaction for this scene (north_star: "only if rocprof shows divergence losses";
+    profiles/r03_config4.md), and two renders have the same bits."""
+    z = load_golden("image_glass_120x80_2000spp.npz")
+    scene = {k[len("scene_"):]: z[k] for k in z.files if k.startswith("scene_")}
+    assert np.bincount(scene["mat_type"])[3] > 200
+    gsum, gspp, depth = z["rgb_sum"], int(z["spp"]), int(z["depth"])
+    gseg = float(z["segments"]) / (120 * 80 * gspp)
+    ctx = rt.Context(0)
+    ctx.set_scene(scene)
+    W, H, spp = 120, 80, 500
+    img, st = ctx.render(rt.stock_camera(W / H), W, H, spp, depth, seed=77)
+    a, b = po.quantise(img, spp), po.quantise(gsum, gspp)
+    psnr, rmse = po.psnr_u8(a, b), rmse_u8(a, b)
+    print("configs[4]: PSNR %.2f dB, 8-bit RMSE %.3f, rays/sample %.3f (oracle %.3f)" % (psnr, rmse, st["rays"] / st["samples"], gseg))
+    assert psnr >= PSNR_MIN_DB and rmse <= RMSE_MAX_8BIT
+    assert np.allclose((img / spp).mean((0, 1)), (gsum / gspp).mean((0, 1)), rtol=5e-3)
+    assert abs(st["rays"] / st["samples"] - gseg) < 0.01 * gseg
+    W, H, spp = 1200, 800, 60
+    cam = rt.stock_camera(W / H)
+    f1, s1 = ctx.render(cam, W, H, spp, depth, seed=3)
+    f2, s2 = ctx.render(cam, W, H, spp, depth, seed=3)
+    ctx.close()
+    assert s1["rays"] / s1["lane_slots"] >= 0.9
+    assert s1["rays"] == s2["rays"] and np.array_equal(bits(f1), bits(f2))
+
+
 def test_render_argument_errors(gpu_ctx):
     cam = rt.stock_camera(1.5)
     with pytest.raises(rt.RtkError, match="divides by"):

@@ -155,6 +155,29 @@ def test_drop_in_executable_writes_the_reference_file(gpu_ctx, tmp_path):
     assert np.abs(got2.astype(int) - want.astype(int)).max() <= 1               # four fp32 partial sums instead of one: last-bit rounding only
 
 
+def test_patched_reference_executable_matches_rtk_render_u8(gpu_ctx, tmp_path):
+    """INTEGRATION.md A carried out (tools/prove_integration.py): the REFERENCE's own sources with the two accessors added
+    and the loops of main.cpp:64-76 replaced by rtk_render, compiled in the build container against librtk.so
+    (oracle/_ref/rtiow_ref_patched).  Its random_scene(), Camera constructor, argv parsing, PPM header and
+    write_color_binary are the reference's; the file it writes must equal rtk_render_u8 of the same arguments byte for byte
+    — which also says that the reference's scene and camera are the ones this repository's host API builds."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(rt.__file__)), "oracle", "_ref", "rtiow_ref_patched")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/rtiow_ref_patched not built (python tools/prove_integration.py, in the build container)")
+    for W, H, spp, depth in ((200, 112, 4, 50), (64, 42, 100, 50)):          # two of the reference's golden-hash argument sets (SURVEY.md 8c)
+        r = subprocess.run([exe, str(W), str(H), str(spp), str(depth)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Image Generation took" in r.stderr and "Done." in r.stderr
+        data = (tmp_path / "image_binary.ppm").read_bytes()
+        header = b"P6\n%d %d\n255\n" % (W, H)
+        assert data.startswith(header) and len(data) == len(header) + W * H * 3
+        got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+        want, _ = gpu_ctx.render_u8(rt.stock_camera(float(np.float32(W) / np.float32(H))), W, H, spp, depth, seed=0)
+        assert np.array_equal(got, want)
+
+
 def test_image_sides_beyond_65535_are_refused(gpu_ctx):
     """The render kernel keeps a pixel's column and row in one register (16 bits each): wider or taller images are
     refused with RTK_ERR_TOO_LARGE before anything is allocated or launched."""

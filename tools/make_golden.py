@@ -325,6 +325,32 @@ def golden_image(W=120, H=80, parts=8, spp_part=250, depth=50):
     print("golden image", W, H, spp, "segments/sample %.4f" % (segs / (W * H * spp)))
 
 
+def _golden_glass_part(args):
+    part, W, H, spp, depth = args
+    from oracle import pyoracle as po
+    o = po.Oracle()
+    o.random_scene(11, 0.1, 0.5)          # BASELINE.json configs[4]: thresholds of main.cpp:130,133 moved to 0.1 / 0.5
+    scene = o.get_scene() if part == 0 else None
+    o.discard(part * 400_000_000, part * 400_000_000 + 7)
+    sums, _, seg = o.render_rows(po.stock_camera(W / H), W, H, spp, depth, want_u8=False)
+    return sums.astype(np.float64), seg, scene
+
+
+def golden_glass_image(W=120, H=80, parts=8, spp_part=250, depth=100):
+    """configs[4] (glass/metal-heavy scene, depth 100): a 2000-spp linear frame from the hash-pinned oracle in 8 decorrelated
+    streams, with the scene it was rendered from (the GPU test uploads exactly these arrays).
+        python tools/make_golden.py --glass"""
+    with mp.get_context("spawn").Pool(min(parts, 8)) as pool:
+        res = pool.map(_golden_glass_part, [(p, W, H, spp_part, depth) for p in range(parts)])
+    total = sum(r[0] for r in res)
+    segs = sum(r[1] for r in res)
+    spp = parts * spp_part
+    scene = res[0][2]
+    np.savez_compressed(os.path.join(GOLD, f"image_glass_{W}x{H}_{spp}spp.npz"), rgb_sum=total.astype(np.float32), spp=np.int32(spp), depth=np.int32(depth),
+                        segments=np.int64(segs), **{"scene_" + k: v for k, v in scene.items()})
+    print("glass golden image", W, H, spp, "depth", depth, "segments/sample %.4f" % (segs / (W * H * spp)), "materials", np.bincount(scene["mat_type"]))
+
+
 def golden_nested():
     """A user scene (not random_scene) in NESTED reference HittableLists (ref_nested_list_hit) with the reference's
     (hit, index, t) for random, tangent and tie rays: what a flatten of nested lists must reproduce through the HIP path."""
@@ -390,6 +416,9 @@ def golden_bands(W=1200, H=800, parts=8, spp_part=250, depth=50, bands=BANDS_120
 
 
 if __name__ == "__main__":
+    if "--glass" in sys.argv:          # only the configs[4] image (added in round 3; the other fixtures are unchanged)
+        golden_glass_image()
+        sys.exit(0)
     if "--nested-only" in sys.argv:
         golden_nested()
         sys.exit(0)
