@@ -112,24 +112,44 @@ struct RenderResult {
 // scanlines at once.  Throws std::runtime_error with rtk_last_error() on failure (there is no CPU fallback).
 //
 // Resumable: with a `checkpoint_path` the running sums and the number of passes done are written to that file after
-// every pass (to a temporary first, then renamed), and a later call with the same path, image size, spp, depth, seed
-// and pass count CONTINUES after the last completed pass instead of starting over — the reference streams pixels to
+// every pass (to a temporary first, then renamed), and a later call with the same path, image size, spp, depth, seed,
+// pass count AND the same scene, camera and accelerator (a hash of them is part of the file) CONTINUES after the last completed pass instead of starting over — the reference streams pixels to
 // its output and loses everything when interrupted (main.cpp:74).  The finished frame has the bits of an
 // uninterrupted one (same passes, same fp32 additions in the same order).  `max_passes_this_call` > 0 stops early
 // (what an interruption looks like to the next call); RenderResult::passes_done tells how far the frame is.
 struct ProgressiveCheckpoint {
     // file layout: this header, then width * height * 3 floats
-    char magic[8];               // "RTKCKPT1"
+    char magic[8];               // "RTKCKPT2"
     int32_t width, height, spp, max_depth, batches, passes_done;
     uint64_t seed;
     uint64_t rays, samples;
+    uint64_t content_hash;       // FNV-1a over the flattened scene arrays, the camera's 22 floats, t_min and the accelerator: a
+                                 // checkpoint of another scene or camera is NOT continued (the two images would be mixed)
 };
+
+// What the pixels depend on besides the header's integers: scene (in list order), camera, t_min, list walk or grid.
+inline uint64_t checkpoint_content_hash(const FlatScene& flat, const rtk_camera& cam, float t_min, int accel) {
+    uint64_t h = 1469598103934665603ull;
+    const auto mix = [&h](const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    const rtk_scene v = flat.view();
+    mix(&v.n, sizeof v.n);
+    const float* arrays[] = {v.cx, v.cy, v.cz, v.radius, v.mat_r, v.mat_g, v.mat_b, v.roughness, v.metallic, v.ior};
+    for (const float* a : arrays) mix(a, sizeof(float) * static_cast<size_t>(v.n));
+    mix(v.mat_type, sizeof(int32_t) * static_cast<size_t>(v.n));
+    mix(&cam, sizeof(float) * 22);
+    mix(&t_min, sizeof t_min);
+    mix(&accel, sizeof accel);
+    return h;
+}
 
 inline bool load_checkpoint(const std::string& path, ProgressiveCheckpoint& h, std::vector<float>& sums) {
     std::ifstream in(path, std::ios_base::binary);
     if (!in) return false;
     in.read(reinterpret_cast<char*>(&h), sizeof h);
-    if (!in || std::memcmp(h.magic, "RTKCKPT1", 8) != 0 || h.width <= 0 || h.height <= 0) return false;
+    if (!in || std::memcmp(h.magic, "RTKCKPT2", 8) != 0 || h.width <= 0 || h.height <= 0) return false;
     sums.resize(static_cast<size_t>(h.width) * h.height * 3);
     in.read(reinterpret_cast<char*>(sums.data()), static_cast<std::streamsize>(sums.size() * sizeof(float)));
     return static_cast<bool>(in);
@@ -171,11 +191,12 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
     if (batches < 1) batches = 1;
     if (batches > samples_per_pixel) batches = samples_per_pixel > 0 ? samples_per_pixel : 1;
     int done = 0, first_pass = 0;
+    const uint64_t content = checkpoint_content_hash(flat, cam, 0.001f, accel);
     if (!checkpoint_path.empty()) {
         ProgressiveCheckpoint h{};
         std::vector<float> sums;
         if (load_checkpoint(checkpoint_path, h, sums) && h.width == image_width && h.height == image_height && h.spp == samples_per_pixel &&
-            h.max_depth == max_depth && h.batches == batches && h.seed == seed && h.passes_done > 0 && h.passes_done <= batches) {
+            h.max_depth == max_depth && h.batches == batches && h.seed == seed && h.content_hash == content && h.passes_done > 0 && h.passes_done <= batches) {
             out.rgb_sum = sums;
             out.stats.rays = h.rays;
             out.stats.samples = h.samples;
@@ -212,7 +233,8 @@ inline RenderResult render_image_progressive(const Hittable& world, const Camera
         out.passes_done = b + 1;
         if (!checkpoint_path.empty()) {
             ProgressiveCheckpoint h{};
-            std::memcpy(h.magic, "RTKCKPT1", 8);
+            std::memcpy(h.magic, "RTKCKPT2", 8);
+            h.content_hash = content;
             h.width = image_width; h.height = image_height; h.spp = samples_per_pixel; h.max_depth = max_depth; h.batches = batches;
             h.passes_done = b + 1; h.seed = seed; h.rays = out.stats.rays; h.samples = out.stats.samples;
             save_checkpoint(checkpoint_path, h, out.rgb_sum);

@@ -125,7 +125,9 @@ void rtk_context_destroy(rtk_context* ctx);
 /* Use an existing HIP stream (a hipStream_t passed as void*) for all work of the context;
  * NULL selects the context's own stream.  For callers that own device memory, e.g. torch.
  * A switch is ordered: work submitted to the new stream waits for what the context queued on the old one (its
- * accumulators, packet queue and run table are shared by consecutive frames). */
+ * accumulators, packet queue and run table are shared by consecutive frames).  Lifetime: the call does not touch the old
+ * stream (the event it waits on was recorded when the work was queued), so a caller may destroy its stream once the work it
+ * queued there is complete or synchronised, and switch afterwards. */
 int rtk_context_set_stream(rtk_context* ctx, void* hip_stream);
 
 /* How the closest hit is found.  No counterpart in the reference, whose HittableList::hit (HittableList.hpp:30-42)
@@ -173,8 +175,9 @@ int rtk_run_schedule(int32_t spp, int32_t width, int32_t height, int32_t run_len
 int rtk_render_tiles_device(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
                             rtk_stats* stats);
 
-/* The same render for callers that CANNOT ALLOCATE device memory — code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  No counterpart in the reference (it has no device).  Arguments, output layout, bits
+/* The same render for callers that CANNOT ALLOCATE device memory — tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb an allocator (it has not been tried under HIP graph capture: the call records timing events
+ * and, on its first use on a device, resolves the array's address).  No counterpart in the reference (it has no device).  Arguments, output layout, bits
  * of the result and asynchrony are those of rtk_render_tiles_device; the difference is where the kernels' working
  * memory lives: pixel accumulators, packet queue, counters and the run table sit in ONE static device array of the
  * library (24 MiB + 8.5 KiB per GPU, held until the process ends) instead of context buffers grown with hipMalloc.
@@ -182,7 +185,10 @@ int rtk_render_tiles_device(rtk_context* ctx, const rtk_camera* cam, const rtk_p
  * run before; pass stats = NULL to also avoid the 32-byte counter read-back and its synchronisation).
  * Limits: at most RTK_NOALLOC_MAX_TILES local tiles (1 048 576 pixels of this rank; 1200 x 800 fits) and 1024 sample
  * runs per pixel -> RTK_ERR_TOO_LARGE beyond.  Every call on a GPU shares that GPU's array: the call clears what it
- * needs at its start, and CALLS THAT OVERLAP ON ONE GPU (two contexts, two streams) RACE — serialise them. */
+ * needs at its start, and CALLS THAT OVERLAP ON ONE GPU (two contexts, two streams) RACE — serialise them.
+ * Statistics: `stats`, when given, are those of THIS call alone (frames = 1); the context's own counters — the frames
+ * rendered through rtk_render_tiles_device since rtk_reset_stats, read by rtk_get_stats — are neither reset nor
+ * advanced by it. */
 #define RTK_NOALLOC_MAX_TILES 16384
 int rtk_render_tiles_device_noalloc(rtk_context* ctx, const rtk_camera* cam, const rtk_params* p, float* d_tile_sums,
                                     rtk_stats* stats);

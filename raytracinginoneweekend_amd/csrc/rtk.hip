@@ -61,14 +61,17 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     return it;
 }
 
-static size_t lds_bytes(bool lds, const SceneDev& sc) {
-    return lds ? static_cast<size_t>(sc.filt_lds + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(kWavesPerBlock) * (sc.npad / 32) * kWave * sizeof(uint32_t)
+static size_t lds_bytes(bool lds, const SceneDev& sc, int waves = kWavesPerBlock) {
+    return lds ? static_cast<size_t>(sc.filt_lds + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(waves) * (sc.npad / 32) * kWave * sizeof(uint32_t)
                : kWavesPerBlock * kStageSpheres * sizeof(float4) + kWavesPerBlock * kListCap * kWave * 2;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.
-template <bool LDS, bool GRID = false>
-__global__ __launch_bounds__(kBlockThreads, 4) void render_kernel(const RenderArgs A) {      // room for 4 workgroups per CU: at most 128 VGPRs
+// WAVES: wavefronts per workgroup.  4 (one per SIMD; up to four workgroups per CU) unless the scene's LDS footprint leaves room
+// for only ONE such workgroup per CU (general words beyond ~600 spheres: tiles 2 KiB per word): then 8, so that the two
+// waves of a SIMD share one copy of the tiles instead of a second workgroup not fitting at all (rtk_set_scene decides).
+template <bool LDS, bool GRID = false, int WAVES = kWavesPerBlock>
+__global__ __launch_bounds__(WAVES * kWave, WAVES == kWavesPerBlock ? 4 : 2) void render_kernel(const RenderArgs A) {      // 4 waves per SIMD: at most 128 VGPRs
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CameraDev s_cam;                                   // 88 B of static LDS next to the dynamic part
     if (threadIdx.x < sizeof(CameraDev) / sizeof(float))
@@ -250,9 +253,11 @@ struct rtk_context {
     hipEvent_t ev_switch = nullptr;                  // orders a new stream behind the old one (rtk_context_set_stream)
     static constexpr int kEventPairs = 256;          // render-kernel brackets of the frames since rtk_reset_stats
     hipEvent_t kev[2 * kEventPairs] = {};
+    hipEvent_t kev_static[2] = {};                   // render-kernel bracket of the last rtk_render_tiles_device_noalloc call (its counters are per call)
     int n_frames = 0;                                // frames since the last reset
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};   // [LDS]
+    int lds_waves = kWavesPerBlock;  // wavefronts per workgroup of render_kernel<true> for the resident scene (4, or 8 for large general-word scenes)
     SceneDev scene = {};
     bool have_scene = false;
     DevBuf filt, wdesc, exact, mat0, mat1;
@@ -282,7 +287,6 @@ struct rtk_context {
 static bool use_lds(const rtk_context* c) { return c->scene.n <= kMaxLdsSpheres; }
 static bool use_grid(const rtk_context* c) { return c->accel == RTK_ACCEL_GRID && c->grid_ok; }
 
-static size_t lds_bytes(bool lds, const SceneDev& sc);
 
 // Builds the uniform grid of the resident scene and uploads it.  A scene a grid cannot hold (build_grid's reasons)
 // leaves grid_ok false with the reason in rtk_last_error(): rendering then walks the list as usual.
@@ -319,7 +323,9 @@ static int upload_grid(rtk_context* c) {
 
 // Counters of the render kernels since they were last cleared (`d_counters`: 4 u64 in device memory) and the HIP-event
 // times of the context's frames.  Synchronises the context's stream.
-static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_counters) {
+// `static_call`: the counters are those of ONE rtk_render_tiles_device_noalloc call (static workspace), timed by kev_static; the
+// context's own frame counter and event ring (the allocating path's frames since rtk_reset_stats) are left alone.
+static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_counters, bool static_call = false) {
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -337,9 +343,15 @@ static int read_stats(rtk_context* c, rtk_stats* stats, const unsigned char* d_c
         stats->drain_frac = (h[5] != 0 && t_last > t0 && t_first >= t0) ? static_cast<float>(static_cast<double>(t_last - t_first) / static_cast<double>(t_last - t0)) : 0.0f;
         stats->reserved_ = 0.0f;
     }
-    stats->frames = static_cast<uint32_t>(c->n_frames);
     stats->kernel_ms = 0.0f;
     stats->total_ms = 0.0f;
+    if (static_call) {
+        stats->frames = 1;
+        stats->frames_timed = 1;
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, c->kev_static[0], c->kev_static[1]));
+        return RTK_OK;
+    }
+    stats->frames = static_cast<uint32_t>(c->n_frames);
     const int timed = c->n_frames < rtk_context::kEventPairs ? c->n_frames : rtk_context::kEventPairs;
     for (int i = 0; i < timed; ++i) {
         float ms = 0.0f;
@@ -385,6 +397,7 @@ int rtk_context_create(int device, rtk_context** out) {
         HIP_TRY(hipEventCreate(&c->ev3));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
         for (hipEvent_t& e : c->kev) HIP_TRY(hipEventCreate(&e));
+        for (hipEvent_t& e : c->kev_static) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(c->control.reserve(512));
         HIP_TRY(hipMemset(c->control.p, 0, 512));
         return RTK_OK;
@@ -409,6 +422,8 @@ void rtk_context_destroy(rtk_context* c) {
     if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
     for (hipEvent_t e : c->kev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->kev_static)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -418,9 +433,10 @@ int rtk_context_set_stream(rtk_context* c, void* hip_stream) {
     hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     if (next != c->stream) {
         // the context's buffers (accumulators, queue, run table) may still be in use by work queued on the old stream:
-        // whatever is submitted to the new stream from now on is ordered behind it
+        // whatever is submitted to the new stream from now on is ordered behind the last such work.  The OLD stream is not
+        // touched here — it may be the caller's and already destroyed; ev_switch was recorded on it when that work was queued
+        // (render_tiles_impl), and a wait on an event that was never recorded returns at once.
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipEventRecord(c->ev_switch, c->stream));
         HIP_TRY(hipStreamWaitEvent(next, c->ev_switch, 0));
         c->stream = next;
     }
@@ -493,6 +509,15 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm)));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm)));
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true>, kBlockThreads, shm));
+            c->lds_waves = kWavesPerBlock;
+            // one 4-wave workgroup per CU would leave each SIMD a single wave: take 8-wave workgroups when they fit
+            const size_t shm8 = lds_bytes(true, c->scene, 2 * kWavesPerBlock);
+            if (nb <= 1 && shm8 + 1024 <= 160 * 1024) {
+                int nb8 = 0;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<true, false, 2 * kWavesPerBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm8)));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, render_kernel<true, false, 2 * kWavesPerBlock>, 2 * kBlockThreads, shm8));
+                if (nb8 >= 1) { c->lds_waves = 2 * kWavesPerBlock; nb = nb8; }
+            }
         } else {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false>, kBlockThreads, shm));
         }
@@ -520,7 +545,7 @@ int rtk_scene_layout(rtk_context* c, int32_t* out4) {
     out4[0] = c->scene.n;
     out4[1] = c->class_words;
     out4[2] = lds ? 1 : 0;
-    out4[3] = static_cast<int32_t>(lds_bytes(lds, c->scene) + sizeof(CameraDev) + 8);     // dynamic + the kernels' static LDS (camera copy)
+    out4[3] = static_cast<int32_t>(lds_bytes(lds, c->scene, lds ? c->lds_waves : kWavesPerBlock) + sizeof(CameraDev) + 8);     // dynamic + the kernels' static LDS (camera copy)
     return RTK_OK;
 }
 
@@ -606,7 +631,6 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
         HIP_TRY(hipMemsetAsync(control, 0, 512, c->stream));
         hipLaunchKernelGGL(runs_kernel, dim3(1), dim3(64), 0, c->stream, p->spp, n_local_px, p->run_len, rt, kNoAllocMaxRuns);
         HIP_TRY(hipGetLastError());
-        c->n_frames = 0;             // the counters are per call here
     } else {
         if (n_acc * 8 > c->accum.cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -647,30 +671,35 @@ static int render_tiles_impl(rtk_context* c, const rtk_camera* cam, const rtk_pa
 
     const bool accel = use_grid(c);
     const bool lds = use_lds(c) && !accel;
-    const size_t shm = lds_bytes(lds, c->scene);
+    const int waves = lds ? c->lds_waves : kWavesPerBlock;
+    const size_t shm = lds_bytes(lds, c->scene, waves);
     A.grid = c->grid;
     int64_t grid = static_cast<int64_t>(c->n_cu) * (accel ? c->blocks_per_cu_grid : c->blocks_per_cu[lds ? 1 : 0]);
-    const int64_t need_blocks = (packets + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t need_blocks = (packets + waves - 1) / waves;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
-    c->last_waves = static_cast<uint64_t>(grid) * kWavesPerBlock;
+    c->last_waves = static_cast<uint64_t>(grid) * waves;
     const int slot = c->n_frames % rtk_context::kEventPairs;
-    HIP_TRY(hipEventRecord(c->kev[2 * slot], c->stream));
+    hipEvent_t k_begin = static_ws ? c->kev_static[0] : c->kev[2 * slot], k_end = static_ws ? c->kev_static[1] : c->kev[2 * slot + 1];
+    HIP_TRY(hipEventRecord(k_begin, c->stream));
     if (accel)
         hipLaunchKernelGGL((render_kernel<false, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
+    else if (lds && waves == 2 * kWavesPerBlock)
+        hipLaunchKernelGGL((render_kernel<true, false, 2 * kWavesPerBlock>), dim3(static_cast<unsigned>(grid)), dim3(2 * kBlockThreads), shm, c->stream, A);
     else if (lds)
         hipLaunchKernelGGL(render_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
     else
         hipLaunchKernelGGL(render_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlockThreads), shm, c->stream, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->kev[2 * slot + 1], c->stream));
-    ++c->n_frames;
+    HIP_TRY(hipEventRecord(k_end, c->stream));
+    if (!static_ws) ++c->n_frames;
     const unsigned fb = static_cast<unsigned>((n_acc + 255) / 256);
     hipLaunchKernelGGL(finalize_kernel, dim3(fb), dim3(256), 0, c->stream, accum, d_tile_sums, n_acc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev3, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_switch, c->stream));      // what a later stream switch has to wait for (rtk_context_set_stream)
     if (stats) {
-        if (int e = read_stats(c, stats, control + 256)) return e;
+        if (int e = read_stats(c, stats, control + 256, static_ws != nullptr)) return e;
         HIP_TRY(hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
     }
     return RTK_OK;

@@ -23,6 +23,7 @@
 
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -61,7 +62,15 @@ int main(int argc, char** argv) {
     HittableList world = random_scene();
     Camera camera{Point3{13.0f, 2.0f, 3.0f}, Point3{0.0f, 0.0f, 0.0f}, Vector3{0.0f, 1.0f, 0.0f}, 20, aspect_ratio, 0.1f, 10.0f};
 
-    std::ofstream bin_file("image_binary.ppm", std::ios_base::binary);
+    if (devices.size() > 1 && (batches > 1 || !checkpoint.empty() || max_passes > 0)) {
+        std::cerr << "error: progressive passes, checkpoints and max_passes are single-device options; a device list renders the frame in one pass\n";
+        return 2;
+    }
+    // The file is opened only when the frame is complete: the reference truncates image_binary.ppm before rendering
+    // (main.cpp:59) and leaves a partial file when interrupted; a run that stops early here (exit status 3, an error)
+    // leaves the previous file untouched.
+    std::ostringstream frame_bytes(std::ios_base::binary);
+    std::ostream& bin_file = frame_bytes;
     try {
         rtk_stats stats{};
         {
@@ -92,6 +101,13 @@ int main(int argc, char** argv) {
         std::cerr << "\nerror: " << e.what() << '\n';
         return 1;
     }
-    bin_file.close();
+    std::ofstream out_file("image_binary.ppm", std::ios_base::binary);
+    const std::string payload = frame_bytes.str();
+    out_file.write(payload.data(), static_cast<std::streamsize>(payload.size()));
+    out_file.close();
+    if (!out_file) {
+        std::cerr << "error: cannot write image_binary.ppm\n";
+        return 1;
+    }
     return 0;
 }

@@ -129,6 +129,35 @@ def test_repeated_mixed_radii_frames_are_bit_identical():
     assert sg["rays"] == st0["rays"] and np.array_equal(bits(g), bits(first))
 
 
+def test_large_general_scene_runs_eight_wave_workgroups_and_matches_the_grid():
+    """1000 spheres of varied radius: 32 general words = 64 KiB of tiles; with four waves per workgroup only ONE workgroup fits
+    a CU (113 KiB) and every SIMD is left a single wave, so rtk_set_scene picks the 8-wave instantiation of the render
+    kernel (one copy of the tiles, two waves per SIMD: 144 KiB).  Same results: the frame equals the uniform-grid kernel's
+    bit for bit, the intersect entry point (always 4 waves) equals the oracle."""
+    s = rt.mixed_radii_scene(1000, seed=3, extent=12.0)
+    ctx = rt.Context(0)
+    ctx.set_scene(s)
+    lay = ctx.scene_layout()
+    assert lay["lds_resident"] and 140000 < lay["lds_bytes_per_workgroup"] <= 160 * 1024 - 1024
+    W, H, spp = 600, 400, 16
+    cam = rt.stock_camera(W / H)
+    a, sa = ctx.render(cam, W, H, spp, 50, seed=4)
+    a2, sa2 = ctx.render(cam, W, H, spp, 50, seed=4)
+    assert np.array_equal(bits(a), bits(a2)) and sa["rays"] == sa2["rays"]
+    rng = np.random.default_rng(12)
+    n = 200_000
+    rays = np.concatenate([rng.uniform(-12, 12, (n, 3)), rng.normal(size=(n, 3))], 1).astype(np.float32)
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.1 + 0.01
+    o = po.Oracle(); o.set_scene(s)
+    hit, idx, t = ctx.intersect(rays)
+    ho, io, to = o.intersect(rays)
+    assert np.array_equal(hit, ho) and np.array_equal(idx, io) and np.array_equal(bits(t), bits(to))
+    assert ctx.set_accel(rt.ACCEL_GRID) == rt.ACCEL_GRID
+    b, sb = ctx.render(cam, W, H, spp, 50, seed=4)
+    ctx.close()
+    assert sa["rays"] == sb["rays"] and np.array_equal(bits(a), bits(b))
+
+
 def test_known_bad_loop_form_is_caught():
     """The checks above must be able to fail.  variants/librtk_known_bad.so is the shipped source with one scalar move
     between the two MFMAs of a word (-DRTK_EXP_SCALAR_BETWEEN_MFMAS, built by __graft_entry__.build()): the form that

@@ -178,6 +178,26 @@ def test_patched_reference_executable_matches_rtk_render_u8(gpu_ctx, tmp_path):
         assert np.array_equal(got, want)
 
 
+def test_stream_switch_after_the_old_stream_was_destroyed(stock_scene_golden):
+    """rtk_context_set_stream does not touch the stream it leaves (the caller may have destroyed it): render on a caller's
+    stream, synchronise, destroy that stream, switch back to the context's own — no error, and the next frame is right."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    ctx = rt.Context(0)
+    ctx.set_scene(stock_scene_golden)
+    cam = rt.stock_camera(1.5)
+    ref, _ = ctx.render(cam, 96, 64, 8, 50, seed=6)
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    ctx.set_stream(stream.value)
+    a, _ = ctx.render(cam, 96, 64, 8, 50, seed=6)                    # synchronises: stats are read back
+    assert hip.hipStreamDestroy(stream) == 0
+    ctx.set_stream(0)                                                  # old stream is gone
+    b, _ = ctx.render(cam, 96, 64, 8, 50, seed=6)
+    ctx.close()
+    assert np.array_equal(bits(a), bits(ref)) and np.array_equal(bits(b), bits(ref))
+
+
 def test_image_sides_beyond_65535_are_refused(gpu_ctx):
     """The render kernel keeps a pixel's column and row in one register (16 bits each): wider or taller images are
     refused with RTK_ERR_TOO_LARGE before anything is allocated or launched."""

@@ -81,3 +81,20 @@ def test_drop_in_executable_resumes_from_its_checkpoint(tmp_path):
     # a checkpoint of other parameters is ignored: the frame starts over and still ends in the same file
     r = subprocess.run([exe, "64", "42", "20", "50", "8", "0", "5", "0", "frame.ckpt"], cwd=b, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and (b / "image_binary.ppm").read_bytes() != whole
+
+
+def test_checkpoint_of_another_scene_setup_is_not_continued_and_partial_runs_leave_no_file(tmp_path):
+    """The checkpoint carries a hash of what the pixels depend on (flattened scene, camera, t_min, accelerator): a file
+    written for the list walk is not continued by a run that asks for the grid — it starts over at pass 1 instead of
+    mixing two renders.  A run that stops early (exit status 3) does not create or truncate image_binary.ppm, and
+    progressive options together with a device list are refused instead of being silently ignored."""
+    exe = os.path.join(os.path.dirname(rt.__file__), "host", "rtiow_amd")
+    args = ["64", "42", "20", "50", "7", "0", "5"]
+    r = subprocess.run([exe, *args, "0", "frame.ckpt", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "stopped after pass 2 of 5" in r.stderr
+    assert not (tmp_path / "image_binary.ppm").exists()
+    r = subprocess.run([exe, *args, "1", "frame.ckpt", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=300)      # accel 1: other content hash
+    assert r.returncode == 3 and "stopped after pass 1 of 5" in r.stderr
+    assert not (tmp_path / "image_binary.ppm").exists()
+    r = subprocess.run([exe, "64", "42", "20", "50", "7", "0,0", "5"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "single-device" in r.stderr

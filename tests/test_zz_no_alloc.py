@@ -59,3 +59,31 @@ def test_noalloc_rejects_sizes_beyond_the_static_array(gpu_ctx):
         gpu_ctx.render_tiles_device_noalloc(cam, p, dummy.data_ptr())
     # the full headline frame fits (1200 x 800 = 15000 tiles)
     assert rt.lib().rtk_local_tile_count(1200, 800, 8, 8, 0, 1) <= 16384
+
+
+def test_noalloc_allocates_nothing_and_leaves_the_context_counters_alone(gpu_ctx):
+    """After a first call (which resolves the static array's address once per device) further calls leave the device's free
+    memory unchanged, also for a LARGER image than any call before (the allocating entry would grow its accumulators).
+    The context's own counters (frames rendered through rtk_render_tiles_device since the last reset) are not touched."""
+    import torch
+    cam = rt.stock_camera(1.5)
+    gpu_ctx.reset_stats()
+    p0 = rt.make_params(96, 64, 4, 50, 1, 0.001, 0, 1, 8, 8, 0, 0)
+    out0 = torch.zeros((rt.lib().rtk_local_tile_count(96, 64, 8, 8, 0, 1), 64, 3), dtype=torch.float32, device="cuda:0")
+    gpu_ctx.render_tiles_device(cam, p0, out0.data_ptr())                      # two frames of the allocating path, counters accumulate
+    gpu_ctx.render_tiles_device(cam, p0, out0.data_ptr())
+    W, H = 1024, 768                                                            # 12288 tiles: larger than anything this context rendered
+    nlt = rt.lib().rtk_local_tile_count(W, H, 8, 8, 0, 1)
+    out = torch.zeros((nlt, 64, 3), dtype=torch.float32, device="cuda:0")
+    p = rt.make_params(W, H, 2, 50, 2, 0.001, 0, 1, 8, 8, 0, 0)
+    gpu_ctx.render_tiles_device_noalloc(cam, rt.make_params(64, 64, 1, 5, 0, 0.001, 0, 1, 8, 8, 0, 0), out.data_ptr())      # first use on this device
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    st = gpu_ctx.render_tiles_device_noalloc(cam, p, out.data_ptr(), want_stats=True)
+    gpu_ctx.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    assert st["samples"] == W * H * 2 and st["frames"] == 1
+    own = gpu_ctx.get_stats()
+    assert own["frames"] == 2 and own["samples"] == 2 * 96 * 64 * 4
