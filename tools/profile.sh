@@ -1,13 +1,15 @@
 #!/bin/bash
-# tools/profile.sh <tag> — rocprofv3 evidence for bench.py's workload on the GPU box.
+# tools/profile.sh <tag> [bench.py arguments] — rocprofv3 evidence for bench.py's workload on the GPU box.
 # One run per pass (rocprofv3 does not split counters over passes; --pmc is never combined with other traces).
 # Results land under gpurun_out/prof_<tag>/; tools/summarize_profile.py turns them into profiles/<tag>_*.
 set -u
 TAG=${1:-r01}
+shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# further arguments go to bench.py (e.g. --glass --depth 100 for BASELINE.json configs[4])
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 echo "== kernel trace + stats" 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 grep '"metric"' $OUT/trace.log > $OUT/trace_bench.json

@@ -52,7 +52,8 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "pmc*_counter_collection.csv
 
 # ---- the code object of the profiled library
 co = kernel_info(lib_path)
-want = "render_kernel<true, false>" if kernel == "render_kernel<true>" else "render_kernel<false, false>" if kernel == "render_kernel<false>" else kernel
+# the 4-wave instantiation (the 8-wave one serves large general-word scenes only)
+want = "render_kernel<true, false, 4>" if kernel == "render_kernel<true>" else "render_kernel<false, false, 4>" if kernel == "render_kernel<false>" else kernel
 ck = next((v for k, v in co.items() if want in k), None)
 if ck is None:
     raise SystemExit(f"{want} not found in {lib_path}: {list(co)}")
@@ -116,7 +117,10 @@ lines = [
     f"| occupancy limits (waves per SIMD) | by VGPRs {waves_by_vgpr}, by LDS {min(8, waves_by_lds)} -> {min(waves_by_vgpr, waves_by_lds, 8)}; measured {g('SQ_WAVES') / N_SIMD:.1f} ({g('SQ_WAVES'):.0f} waves per launch, persistent: all resident for the whole kernel) | code object, SQ_WAVES |",
     f"| effective clock | {clock_ghz:.2f} GHz | GRBM_GUI_ACTIVE / 8 / duration |",
     f"| VALU wave-instructions per launch | {valu:.3e} = {valu / wave_passes:.0f} per wavefront pass ({filt_txt}) | SQ_INSTS_VALU, passes = rays / 64 / lane utilisation ({roof['lane_utilisation']:.4f}) |",
-    f"| VALU issue utilisation | {valu / N_SIMD * 2 / cyc if cyc else float('nan'):.3f} (2 cycles per wave64 VALU instruction per SIMD) | SQ_INSTS_VALU x 2 / (SIMDs x cycles) |",
+    f"| VALU issue utilisation | {valu / N_SIMD * 2 / cyc if cyc else float('nan'):.3f} if every vector instruction took the 2 cycles of a full-rate one | SQ_INSTS_VALU x 2 / (SIMDs x cycles) |",
+    f"| VALU pipe occupancy from the instruction mix | **{(2 * (fma + add + mul) + 8 * trans + 4 * max(0.0, valu - fma - add - mul - trans)) / N_SIMD / cyc if cyc else float('nan'):.2f}** of the SIMD cycles: fp32 FMA/ADD/MUL at 2 cycles, transcendentals at 8, "
+    f"everything else (conversions, compares, selects, shifts, lane swaps, 64-bit multiplies: {max(0.0, valu - fma - add - mul - trans) / max(1.0, valu) * 100:.0f} % of the instructions) at the 4 cycles measured for them "
+    "(profiles/r02_valu_findings.md; the few full-rate integer forms — and/or/xor/mov/add — are priced at 4 too, so this is an upper estimate): the kernel is bound by vector issue, and half of that is half-rate integer work | SQ_INSTS_VALU_* |",
     f"| matrix pipe | busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / N_SIMD / cyc if cyc else float('nan'):.3f} of SIMD cycles = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 / wave_passes:.1f} MFMAs of 32 cycles per wavefront pass; "
     f"executed f16 matrix flops {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 1e12:.0f} TF/s = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 32 * 32768 / (avg_ms * 1e-3) / 2.5e15:.3f} of the 2.5 PF dense f16 peak; "
     + (f"a vector instruction executes during {coexec_c / max(1.0, mfma_busy_c):.2f} of the matrix cycles (co-execution {coexec:.3f} of SIMD cycles): the two pipes run side by side, "
