@@ -29,7 +29,8 @@ namespace rtk {
 // and from the uniform-grid kernel's.  Found by editing single instructions of the built code object
 // (tools/asm_variant.py, tools/hazard_hunt/): the shipped loop with one s_mov_b32 s, s moved between its two MFMAs
 // fails, with s_nop or a vector move in the same place it is exact, and with the second MFMA reading a COPY of the A
-// fragment in other registers it is exact again.  Which of the loop's instructions the compiler's scheduler puts
+// fragment in other registers — or the same registers rewritten onto themselves by a vector move in between — it is
+// exact again.  Which of the loop's instructions the compiler's scheduler puts
 // between two builtin MFMAs is not under the source's control (three source forms of rounds 2 scheduled the loop
 // compare there), so the MFMAs of one word are ONE asm statement: nothing can be scheduled between them, the result
 // tiles are early-clobber outputs (a 32x32 result must not overlap its A or B operand: the matrix pipe reads them over

@@ -1,6 +1,7 @@
 """tools/atomics_ab.py — what do the u64 accumulator atomics cost?  Kernel time of rank 0 of `world` ranks of the
 1200x800x500 frame with the shipped library and with a build whose atomics are removed (-DRTK_EXP_NO_ATOMICS: wrong image,
-timing only); run once per library (RTK_LIB).   usage: RTK_LIB=... python tools/atomics_ab.py [world ...]"""
+timing only; the switch was a temporary edit of rtk_render.hpp's flush, `atomicAdd(p, v)` -> nothing, and is not in the tree:
+profiles/r03_atomics_ab.txt has the result); run once per library (RTK_LIB).   usage: RTK_LIB=... python tools/atomics_ab.py [world ...]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
