@@ -149,7 +149,9 @@ int rtk_accel_in_use(rtk_context* ctx);
  * in the reference): out4 = { spheres, CLASS words (32 consecutive list entries whose filterable spheres share cy and
  * radius — every small sphere of random_scene(), main.cpp:124, qualifies — so that their filter test is 15 terms of one
  * dot product: two v_mfma_f32_32x32x16_f16 per word of 32 spheres x 64 rays instead of four for a general word),
- * 1 if the scene is LDS-resident (at most 1024 spheres), LDS bytes per workgroup of the render kernel }. */
+ * 1 if the scene is LDS-resident (at most 1024 spheres), LDS bytes per workgroup of the render kernel }.  For a larger scene
+ * the second number counts the words that have a tile in their own frame (0: the scene streams through the vector-ALU
+ * filter; otherwise the matrix-pipe filter runs per word in word-local coordinates). */
 int rtk_scene_layout(rtk_context* ctx, int32_t* out4);
 
 /* Upload the flattened world.  Replaces the traversal state HittableList::hit walks

@@ -13,7 +13,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -53,6 +55,9 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
         it.exact = sc.exact;
         it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
         it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
+        it.ltiles = sc.ltiles;
+        it.lwdesc = sc.lwdesc;
+        it.lwords = sc.lwords;
     }
     it.n = sc.n;
     it.fb = sc.fb;
@@ -260,10 +265,11 @@ struct rtk_context {
     int lds_waves = kWavesPerBlock;  // wavefronts per workgroup of render_kernel<true> for the resident scene (4, or 8 for large general-word scenes)
     SceneDev scene = {};
     bool have_scene = false;
-    DevBuf filt, wdesc, exact, mat0, mat1;
+    DevBuf filt, wdesc, exact, mat0, mat1, ltiles, lwdesc;
     SceneDev scene_flat = {};   // the same scene in the streamed layout: what the kernels that do not keep it in LDS read (large scenes: == scene; small scenes under the grid)
     DevBuf filt_flat;
     int class_words = 0;     // words of 32 spheres with 8-byte class records (rtk_scene_layout)
+    int local_words = 0;     // streamed scenes: words with a tile in their own frame (0: the vector-ALU walk)
     uint64_t last_waves = 0; // wavefronts of the last render launch
     DevBuf runs;         // sample partition table of the current (spp, W, H, run_len)
     std::vector<uint2> runs_host;
@@ -414,7 +420,7 @@ void rtk_context_destroy(rtk_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->filt, &c->filt_flat, &c->wdesc, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+    for (DevBuf* b : {&c->filt, &c->filt_flat, &c->wdesc, &c->ltiles, &c->lwdesc, &c->exact, &c->mat0, &c->mat1, &c->runs, &c->accum, &c->control, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->scratch_d, &c->scratch_e, &c->tile_out, &c->image_out, &c->image_u8, &c->g_cells, &c->g_items, &c->g_always})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -483,6 +489,18 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
         HIP_TRY(hipMemcpy(c->wdesc.p, ps.wdesc.data(), sizeof(float4) * ps.wdesc.size(), hipMemcpyHostToDevice));
         c->scene.wdesc = static_cast<const float4*>(c->wdesc.p);
     }
+    c->local_words = 0;
+    // streamed scene of class words: the matrix-pipe filter in word-local frames (the variable: A/B measurements against the staged vector-ALU walk)
+    if (ps.use_local && !std::getenv("RTK_NO_LOCAL_FRAMES")) {
+        HIP_TRY(c->ltiles.reserve(sizeof(float4) * ps.ltiles.size()));
+        HIP_TRY(c->lwdesc.reserve(sizeof(float4) * ps.lwdesc.size()));
+        HIP_TRY(hipMemcpy(c->ltiles.p, ps.ltiles.data(), sizeof(float4) * ps.ltiles.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->lwdesc.p, ps.lwdesc.data(), sizeof(float4) * ps.lwdesc.size(), hipMemcpyHostToDevice));
+        c->scene.ltiles = static_cast<const float4*>(c->ltiles.p);
+        c->scene.lwdesc = static_cast<const float4*>(c->lwdesc.p);
+        c->scene.lwords = ps.local_words;
+        c->local_words = ps.local_class_words;
+    }
     c->scene_flat = c->scene;
     if (compact) {
         // the grid kernels do not keep the scene in LDS; their fallback for rays the grid cannot serve streams the list
@@ -543,7 +561,7 @@ int rtk_scene_layout(rtk_context* c, int32_t* out4) {
     if (!c->have_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scene_layout: call rtk_set_scene first");
     const bool lds = use_lds(c) && !use_grid(c);
     out4[0] = c->scene.n;
-    out4[1] = c->class_words;
+    out4[1] = use_lds(c) ? c->class_words : c->local_words;
     out4[2] = lds ? 1 : 0;
     out4[3] = static_cast<int32_t>(lds_bytes(lds, c->scene, lds ? c->lds_waves : kWavesPerBlock) + sizeof(CameraDev) + 8);     // dynamic + the kernels' static LDS (camera copy)
     return RTK_OK;

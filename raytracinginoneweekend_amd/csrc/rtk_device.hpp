@@ -156,6 +156,12 @@ struct SceneDev {
     const float4* wdesc = nullptr;   // [npad / 32]
     int32_t filt_len = 0;            // float4 entries of filt
     int32_t filt_lds = 0;            // matrix-pipe layout: entries of filt that the kernels keep in LDS (all of it)
+    // Streamed scenes whose words are (nearly) all class words in their OWN frame (local_term below): per word a 64-fragment
+    // tile and two float4 of descriptor; null when the scene streams through the vector-ALU filter alone.
+    // The list is cut into `lwords` words of at most 32 consecutive entries (rtk_scene_prep.hpp).
+    const float4* ltiles = nullptr;  // [lwords][64]
+    const float4* lwdesc = nullptr;  // [lwords][3]: (frame centre x, y, z, sigma_w) (K0, 2 * first entry + kind, always bits, valid bits) (entries, -, -, -)
+    int32_t lwords = 0;
 };
 constexpr int kShortTail = 8;
 
@@ -190,6 +196,49 @@ __host__ __device__ inline void quad_term(int k, int n_mono, int& mono, int& sph
 __host__ __device__ inline int tile_row_sphere(int rho) {
     const int hf = (rho >> 2) & 1, r = rho - 4 * hf, c = r & 1, m = 2 * (r >> 3) + ((r >> 1) & 1);
     return 16 * hf + 8 * c + m;
+}
+// ---- word-local frames: the matrix-pipe filter for scenes beyond LDS --------------------------------
+// In scene-scaled units a 0.2-unit sphere of a 10 000-sphere scene has r'^2 ~ 8e-6, below what 16 fp32 accumulation steps
+// resolve (2^-19 T, T ~ 2).  So every word of 32 consecutive spheres that share cy and radius gets its OWN frame: centre c_w
+// (cy exactly, the middle of the word's x and z ranges) and a power of two sigma_w with sigma_w |C - c_w|_inf <= kLocalB and
+// sigma_w r~ <= kLocalB.  With delta = sigma_w (C - c_w) (delta_y = 0), v = sigma_w (o - c_w), p = v - (v.d) d:
+//     P = qxx dx^2 + qzz dz^2 + qxz' dx dz - 2 px dx - 2 pz dz + |p|^2        (the class word's five monomials, cy' = 0)
+// The three quadratic coefficients are the ray's alone (built once per pass); the two linear ones and the constant depend on
+// the word: ~35 vector instructions per word rebuild their f16 parts and the constant, against the 192 that the
+// vector-ALU form spends on the word's 32 tests beyond the 64 both need.  Term order of a local tile (local_term): the six
+// terms of the linear coefficients sit in B dwords lo[2], lo[3], hi[3], so that two lane swaps per word rebuild the B
+// operands.  Margin (all in the word's scaled units, u = 2^-24):
+//   evaluation: kQuadEpsClass T,  T <= 3 B^2 + sqrt(2) B + r~'^2 + (1 + sqrt(2) B) |p|^2     (2 B (|px| + |pz|) <= sqrt(2) B (1 + |p|^2))
+//   the reference's own rounding: 2^-19 T1,  T1 = |v - delta|^2 + r'^2 <= 1.25 |v|^2 + 10 B^2 + r'^2
+//   v, v.d, p, |p|^2 in fp32: u |v| (28 |p| + 25) <= 2^-19 (0.5 |v|^2 + 0.81 |p|^2 + 0.64)
+//   => marg = 1.25 (sum) + 2^-21 = A0_w + kLocalA1 |p|^2 + kLocalA2 |v|^2,   K = |p|^2 - r~'^2 - marg.
+// |p| is clamped to 2 per component for the coefficients (|2 p| 2^13 must stay an f16 number): a clamped ray passes at
+// least 2 - sqrt(2) B > 1 from every centre of the word while r~'^2 + marg < B^2 + 0.1 for |v|^2 < kLocalSafeVV, so its
+// (wrong) sums are still positive; beyond kLocalSafeVV, or NaN, the lane takes every sphere of the word.
+constexpr float kLocalB = 0.625f;
+constexpr float kLocalSafeVV = 0x1p14f;
+constexpr double kLocalReach = 100.0;      // a class word's centres stay within this many radii of its frame centre (host cut)
+constexpr float kLocalA1 = 1.25f * ((1.0f + 1.41422f * kLocalB) * kQuadEpsClass + 0.81f * 0x1p-19f);
+constexpr float kLocalA2 = 1.25f * 1.75f * 0x1p-19f;
+// the word's part of the margin, given its scaled widened radius^2 (host, rounded up by the caller)
+inline double local_margin_const(double r2s) {
+    const double B = kLocalB;
+    return 1.25 * (static_cast<double>(kQuadEpsClass) * (3.0 * B * B + 1.41422 * B + r2s) + 0x1p-19 * (10.0 * B * B + 0.64 + r2s)) + 0x1p-21;
+}
+// term k of a local tile row: monomial (0 xx, 1 zz, 2 xz, 3 x, 4 z; -1 unused), part of the sphere's monomial, part of the ray's coefficient
+__host__ __device__ inline void local_term(int k, int& mono, int& sphere_part, int& ray_part) {
+    const int idx = k < 4 ? k : (k >= 8 && k <= 12 ? k - 4 : -1);          // the nine quadratic terms: k = 0..3, 8..12
+    sphere_part = 0; ray_part = 0;
+    if (idx >= 0) { mono = idx / 3; sphere_part = (idx % 3) == 2; ray_part = (idx % 3) == 1; return; }
+    switch (k) {
+        case 4: mono = 3; break;
+        case 5: mono = 3; ray_part = 1; break;
+        case 6: mono = 3; sphere_part = 1; break;
+        case 7: mono = 4; sphere_part = 1; break;
+        case 14: mono = 4; break;
+        case 15: mono = 4; ray_part = 1; break;
+        default: mono = -1;
+    }
 }
 // float -> IEEE binary16 bits, round to nearest even (overflow -> inf; subnormals kept), and back
 __host__ __device__ inline uint16_t f16_rne(float v) {

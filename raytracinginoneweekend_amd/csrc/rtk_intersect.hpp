@@ -107,6 +107,9 @@ struct Intersector {
     uint16_t* list;        // !LDS: this wave's candidate list in LDS: [kListCap][64]
     uint32_t* masks = nullptr;   // LDS: this wave's candidate mask words in LDS: [npad / 32][64]
     float4* stage = nullptr;     // !LDS: this wave's LDS chunk of kStageSpheres filter operands
+    const float4* ltiles = nullptr;   // !LDS: word-local tiles (SceneDev::ltiles) or null: the staged vector-ALU walk
+    const float4* lwdesc = nullptr;   // !LDS: their descriptors
+    int lwords = 0;                   // !LDS: words of the local cut
     FilterBounds fb;
     int n;
     int lane;
@@ -149,6 +152,28 @@ struct Intersector {
         const float dd = fmaf(p2, p2, fmaf(p1, p1, -sw));
         m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd), 31);
     }
+#ifndef RTK_HOST_EMULATION
+    // 16 results of a lane -> 16 mask bits, first sphere in the highest bit: registers 2 m hold spheres 16 hf + m,
+    // registers 2 m + 1 spheres 16 hf + 8 + m; one fp32 accumulator (16 bits: exact).  X = clamp(-2^48 D + k) is exactly 1.0
+    // for a candidate, else 0.0.
+    static __device__ __forceinline__ uint32_t mfma_bits16(const rtk_f32x16& d, float k) {
+        const float nbig = -0x1p48f;
+        float acc = __builtin_amdgcn_fmed3f(fmaf(d[0], nbig, k), 0.0f, 1.0f);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) {
+            const int reg = e < 8 ? 2 * e : 2 * (e - 8) + 1;
+            acc = fmaf(acc, 2.0f, __builtin_amdgcn_fmed3f(fmaf(d[reg], nbig, k), 0.0f, 1.0f));
+        }
+        return static_cast<uint32_t>(acc);
+    }
+    // h0 / h1: the 16 bits of this lane's spheres for the ray of lane (lane & 31) / (lane | 32).  After the swap a
+    // lane holds both halves of its own ray's word: spheres 0..15 (from the lower lane half) and 16..31.
+    static __device__ __forceinline__ uint32_t mfma_join(uint32_t h0, uint32_t h1) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(h0, h1, false, false);
+        return (sw[0] << 16) | sw[1];
+    }
+#endif
     // `n_exact`: the WAVE's running total of exact tests (every lane holds the same number).
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
                                                 uint32_t& n_exact) const {
@@ -416,24 +441,8 @@ struct Intersector {
                 kcg[0] = __uint_as_float(a1[0]); kcg[1] = __uint_as_float(a1[1]);
                 kgg[0] = __uint_as_float(a2[0]); kgg[1] = __uint_as_float(a2[1]);
             }
-            const float nbig = -0x1p48f;
-            // 16 results of a lane -> 16 mask bits, first sphere in the highest bit: registers 2 m hold spheres 16 hf + m,
-            // registers 2 m + 1 spheres 16 hf + 8 + m; one fp32 accumulator (16 bits: exact)
-            auto bits16 = [&](const f32x16& d, float k) {
-                float acc = __builtin_amdgcn_fmed3f(fmaf(d[0], nbig, k), 0.0f, 1.0f);
-#pragma unroll
-                for (int e = 1; e < 16; ++e) {
-                    const int reg = e < 8 ? 2 * e : 2 * (e - 8) + 1;
-                    acc = fmaf(acc, 2.0f, __builtin_amdgcn_fmed3f(fmaf(d[reg], nbig, k), 0.0f, 1.0f));
-                }
-                return static_cast<uint32_t>(acc);
-            };
-            // h0 / h1: the 16 bits of this lane's spheres for the ray of lane (lane & 31) / (lane | 32).  After the swap a
-            // lane holds both halves of its own ray's word: spheres 0..15 (from the lower lane half) and 16..31.
-            auto join = [&](uint32_t h0, uint32_t h1) {
-                const u32x2 sw = __builtin_amdgcn_permlane32_swap(h0, h1, false, false);
-                return (sw[0] << 16) | sw[1];
-            };
+            auto bits16 = [](const f32x16& d, float k) { return mfma_bits16(d, k); };
+            auto join = [](uint32_t h0, uint32_t h1) { return mfma_join(h0, h1); };
             if (!has_general) {
                 // every tile is a class tile: word w's fragments are filt[64 w ...]
                 f16x8 bc[2];
@@ -540,6 +549,143 @@ struct Intersector {
             prof[1] += __builtin_readcyclecounter() - pt1;
 #endif
         };
+        // Scenes beyond LDS whose words have local tiles (rtk_device.hpp "word-local frames"): per word the ray's linear
+        // coefficients and constant are rebuilt in the word's frame (~35 vector instructions), then the class word's two MFMAs
+        // and 64 FMAs as above; the A fragment comes straight from global memory (16 bytes per lane, the next word's requested
+        // a word ahead), the descriptor through the scalar cache.  Words without a tile (kind 0: mixed radii, the list's
+        // ragged end) run the projection form on the vector ALUs with the spheres as scalar operands.
+        auto scan_local = [&]() {
+            const bool safe_ray = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+            const int words = lwords;
+            // the quadratic coefficients: the ray's alone
+            const float qc[3] = {fmaf(dy, dy, dz * dz) * kQuadRayScale, fmaf(dx, dx, dy * dy) * kQuadRayScale, -2.0f * dx * dz * kQuadRayScale};
+            uint16_t qp[3][2];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) f16_split2(qc[m], qp[m]);
+            // B terms of this ray, k = 0..15 (local_term): the linear ones are filled in per word
+            auto term = [&](int k, const uint16_t (&lp)[2][2]) -> uint32_t {
+                int mono, sp, rp;
+                local_term(k, mono, sp, rp);
+                return mono < 0 ? 0u : (mono < 3 ? qp[mono][rp] : lp[mono - 3][rp]);
+            };
+            const uint16_t zero_l[2][2] = {{0, 0}, {0, 0}};
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                lo[d] = term(2 * d, zero_l) | (term(2 * d + 1, zero_l) << 16);
+                hi[d] = term(8 + 2 * d, zero_l) | (term(9 + 2 * d, zero_l) << 16);
+            }
+#ifdef RTK_HOST_EMULATION
+            typedef const float4* ConstQuads;
+            const ConstQuads desc = lwdesc, src = filt;
+#else
+            typedef float Quad __attribute__((ext_vector_type(4)));
+            typedef const Quad __attribute__((address_space(4))) * ConstQuads;
+            const ConstQuads desc = (ConstQuads)(lwdesc), src = (ConstQuads)(filt);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            // B fragments: lane l supplies B[k = 8 (l >> 5) + j][column l & 31]; dword d of the two ray groups is
+            // v_permlane32_swap(lo[d], hi[d]).  Dwords 0 and 1 hold quadratic terms only: swapped once per pass.
+            u32x4 g0, g1;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+                g0[d] = sw[0]; g1[d] = sw[1];
+            }
+            float4 av_next = ltiles[lane];
+#endif
+            for (int w = 0; w < words; ++w) {
+                const auto d0 = desc[3 * w], d1 = desc[3 * w + 1], d2 = desc[3 * w + 2];
+#ifndef RTK_HOST_EMULATION
+                const float4 av = av_next;
+                av_next = ltiles[(w + 1 < words ? w + 1 : w) * 64 + lane];
+                const int start_kind = __builtin_amdgcn_readfirstlane(__float_as_int(d1.y)), count = __builtin_amdgcn_readfirstlane(__float_as_int(d2.x));
+#else
+                const int start_kind = __float_as_int(d1.y), count = __float_as_int(d2.x);
+#endif
+                const bool cls = (start_kind & 1) != 0;
+                const int base = start_kind >> 1;
+                if (base - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
+                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
+                    list_base = base;
+                }
+                const uint32_t always = __float_as_uint(d1.z), valid = __float_as_uint(d1.w);
+                uint32_t m = 0;
+                bool judged = safe;
+                if (cls) {
+                    // the ray in the word's frame
+                    const float sg = d0.w;
+                    const float vx = (r.o.x - d0.x) * sg, vy = (r.o.y - d0.y) * sg, vz = (r.o.z - d0.z) * sg;
+                    const float sd = fmaf(vz, dz, fmaf(vy, dy, vx * dx));
+                    const float px = fmaf(-sd, dx, vx), py = fmaf(-sd, dy, vy), pz = fmaf(-sd, dz, vz);
+                    const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
+                    const float vv = fmaf(sd, sd, pp);
+                    judged = safe_ray && (vv < kLocalSafeVV);
+                    // constant: (|p|^2 - r~'^2 - marg) 2^27, pushed away from zero so that it is a multiple of 2^-48, then times -2^48
+                    float ks = fmaf(pp, 1.0f - kLocalA1, fmaf(vv, -kLocalA2, d1.x)) * (kQuadSphereScale * kQuadRayScale);
+                    ks = fabsf(ks) < 0x1p-24f ? -0x1p-24f : ks;
+                    const float kc = ks * -0x1p48f;
+                    // linear coefficients -2 p 2^13 from the clamped p, in two f16 parts
+                    const float lx = fminf(fmaxf(px, -2.0f), 2.0f) * (-2.0f * kQuadRayScale), lz = fminf(fmaxf(pz, -2.0f), 2.0f) * (-2.0f * kQuadRayScale);
+                    uint16_t lp[2][2];
+                    f16_split2(lx, lp[0]);
+                    f16_split2(lz, lp[1]);
+                    lo[2] = term(4, lp) | (term(5, lp) << 16);
+                    lo[3] = term(6, lp) | (term(7, lp) << 16);
+                    hi[3] = term(14, lp) | (term(15, lp) << 16);
+#ifdef RTK_HOST_EMULATION
+                    const float4* tile = ltiles + static_cast<size_t>(w) * 64;
+                    uint16_t vb[16];
+                    for (int d = 0; d < 4; ++d) {
+                        vb[2 * d] = static_cast<uint16_t>(lo[d]); vb[2 * d + 1] = static_cast<uint16_t>(lo[d] >> 16);
+                        vb[8 + 2 * d] = static_cast<uint16_t>(hi[d]); vb[9 + 2 * d] = static_cast<uint16_t>(hi[d] >> 16);
+                    }
+                    for (int rho = 0; rho < 32; ++rho) {
+                        const int i = tile_row_sphere(rho);
+                        float dsum = 0.0f;
+                        double exact_sum = 0.0, abs_sum = 0.0;
+                        for (int k = 0; k < 16; ++k) {
+                            const uint16_t* frag = reinterpret_cast<const uint16_t*>(tile + 32 * (k >> 3) + rho);
+                            const float ak = f16_value(frag[k & 7]), bk = f16_value(vb[k]);
+                            dsum = fmaf(ak, bk, dsum);
+                            exact_sum += static_cast<double>(ak) * bk;
+                            abs_sum += std::fabs(static_cast<double>(ak) * bk);
+                        }
+                        if (rtk_shim::ulp_noise > 0 && abs_sum < 1e30)
+                            dsum = static_cast<float>(exact_sum + rtk_shim::ulp_noise / 3.0 * 16 * 0x1p-23 * abs_sum) + 0.0f;
+                        const float x = fmaf(dsum, -0x1p48f, kc);
+                        if (x > 0.0f && x < 1.0f) RTK_STAT_EACH(clamp_fractions);
+                        if (x > 0.0f) m |= 0x80000000u >> i;
+                    }
+#else
+                    u32x2 sw = __builtin_amdgcn_permlane32_swap(lo[2], hi[2], false, false);
+                    g0[2] = sw[0]; g1[2] = sw[1];
+                    sw = __builtin_amdgcn_permlane32_swap(lo[3], hi[3], false, false);
+                    g0[3] = sw[0]; g1[3] = sw[1];
+                    sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(kc), __float_as_uint(kc), false, false);
+                    rtk_f16x8 a0, b0, b1;
+                    __builtin_memcpy(&a0, &av, 16);
+                    __builtin_memcpy(&b0, &g0, 16);
+                    __builtin_memcpy(&b1, &g1, 16);
+                    rtk_f32x16 t0, t1;
+                    mfma_pair(t0, t1, a0, b0, b1);
+                    m = mfma_join(mfma_bits16(t0, __uint_as_float(sw[0])), mfma_bits16(t1, __uint_as_float(sw[1])));
+#endif
+                    m |= always;
+                    RTK_STAT(lane, class_words);
+                } else {
+#pragma unroll 8
+                    for (int i = 0; i < count; ++i) {
+                        const auto sp = src[base + i];
+                        filter_one(f, sp.x, sp.y, sp.z, sp.w, m);
+                    }
+                    m <<= (32 - count);
+                }
+                RTK_STAT(lane, filter_words);
+                const uint32_t cand = (judged ? m : 0xFFFFFFFFu) & valid;
+                emit(base, active ? cand : 0u);
+            }
+        };
         if (!LDS) {
             // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced
             // global load per 64 spheres instead of one broadcast load per sphere — and filters from LDS as usual.
@@ -547,33 +693,37 @@ struct Intersector {
             // visible to its reads and the next chunk's writes cannot overtake this chunk's reads.
             // The next chunk is fetched into registers before the current one is scanned, so its
             // latency hides behind ~1150 filter instructions.
-            constexpr int kPerLane = kStageSpheres / kWave;
+            if (lwdesc != nullptr) {
+                scan_local();
+            } else {
+                constexpr int kPerLane = kStageSpheres / kWave;
 #ifdef RTK_HOST_EMULATION
-            typedef float4 Quad;
+                typedef float4 Quad;
 #else
-            typedef float Quad __attribute__((ext_vector_type(4)));     // a register quad the compiler keeps out of scratch
+                typedef float Quad __attribute__((ext_vector_type(4)));     // a register quad the compiler keeps out of scratch
 #endif
-            const Quad* src = reinterpret_cast<const Quad*>(filt);
-            Quad* dst = reinterpret_cast<Quad*>(stage);
-            Quad pre[kPerLane];
+                const Quad* src = reinterpret_cast<const Quad*>(filt);
+                Quad* dst = reinterpret_cast<Quad*>(stage);
+                Quad pre[kPerLane];
 #pragma unroll
-            for (int j = 0; j < kPerLane; ++j) {
-                const int i = j * kWave + lane;
-                pre[j] = src[i < n ? i : n - 1];
-            }
-            for (int base = 0; base < n; base += kStageSpheres) {
-                const int count = n - base < kStageSpheres ? n - base : kStageSpheres;
-                RTK_WAVE_SYNC();
-#pragma unroll
-                for (int j = 0; j < kPerLane; ++j)
-                    if (j * kWave + lane < count) dst[j * kWave + lane] = pre[j];
-                RTK_WAVE_SYNC();
-#pragma unroll
-                for (int j = 0; j < kPerLane; ++j) {          // unconditional (clamped) loads: no branch, so no wait before the scan
-                    const int i = base + kStageSpheres + j * kWave + lane;
+                for (int j = 0; j < kPerLane; ++j) {
+                    const int i = j * kWave + lane;
                     pre[j] = src[i < n ? i : n - 1];
                 }
-                scan([&](int i) { return stage[i]; }, base, count);
+                for (int base = 0; base < n; base += kStageSpheres) {
+                    const int count = n - base < kStageSpheres ? n - base : kStageSpheres;
+                    RTK_WAVE_SYNC();
+#pragma unroll
+                    for (int j = 0; j < kPerLane; ++j)
+                        if (j * kWave + lane < count) dst[j * kWave + lane] = pre[j];
+                    RTK_WAVE_SYNC();
+#pragma unroll
+                    for (int j = 0; j < kPerLane; ++j) {          // unconditional (clamped) loads: no branch, so no wait before the scan
+                        const int i = base + kStageSpheres + j * kWave + lane;
+                        pre[j] = src[i < n ? i : n - 1];
+                    }
+                    scan([&](int i) { return stage[i]; }, base, count);
+                }
             }
             flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
         } else {

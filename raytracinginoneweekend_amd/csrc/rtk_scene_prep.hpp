@@ -18,6 +18,10 @@ namespace rtk {
 struct PreparedScene {
     std::vector<float4> filt, exact, m0, m1;
     std::vector<float4> wdesc;       // matrix-pipe layout only (SceneDev::wdesc); empty = streamed layout
+    std::vector<float4> ltiles, lwdesc;   // streamed layout: word-local tiles and descriptors (SceneDev::ltiles, lwdesc)
+    int local_words = 0;             // words of the local cut (class words and kind-0 words)
+    int local_class_words = 0;       // those that have a local tile
+    bool use_local = false;          // nearly all full words have one: the streamed walk filters on the matrix pipe
     int class_words = 0;
     int filt_lds = 0;                // SceneDev::filt_lds
     std::vector<char> filterable;    // per sphere: the filter may reject it (finite, moderate, not an outlier)
@@ -98,6 +102,130 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
     out.filterable = filterable;
     out.wdesc.clear();
     out.class_words = 0;
+    out.ltiles.clear();
+    out.lwdesc.clear();
+    out.local_class_words = 0;
+    out.use_local = false;
+    if (!compact) {
+        // Word-local frames (rtk_device.hpp local_term).  The list is cut into words of AT MOST 32 consecutive entries: a class
+        // word grows while its filterable spheres share cy and the widened r^2 bit for bit and stay within kLocalReach radii
+        // of the middle of their x and z ranges (so that sigma_w r stays large enough for the margin: a word that wrapped from
+        // the end of one row of random_scene() to the start of the next would be ten times wider than a row's word); what is
+        // left between class words becomes kind-0 words, filtered on the vector ALUs.
+        auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };
+        struct Span { int start, count; bool cls; float cy, r2, cxw, czw; double reach; };
+        // the class word that would start at i: how many entries, and its frame
+        auto class_run = [&](int i, Span& sp) {
+            sp = {i, 0, false, 0.f, 0.f, 0.f, 0.f, 0.0};
+            bool have = false;
+            float lox = inf, hix = -inf, loz = inf, hiz = -inf;
+            int members = 0;
+            for (int j = i; j < n && j < i + 32; ++j) {
+                if (filterable[j]) {
+                    const float r2j = widened_r2(j);
+                    if (have && !(same_bits(s->cy[j], sp.cy) && same_bits(r2j, sp.r2))) break;
+                    const float nlox = std::fmin(lox, s->cx[j]), nhix = std::fmax(hix, s->cx[j]), nloz = std::fmin(loz, s->cz[j]), nhiz = std::fmax(hiz, s->cz[j]);
+                    const double half = 0.5 * std::max(static_cast<double>(nhix) - nlox, static_cast<double>(nhiz) - nloz);
+                    const double rj = std::sqrt(static_cast<double>(r2j));
+                    if (!(half <= kLocalReach * rj)) break;          // also ends the word at a non-finite extent
+                    if (!have) { sp.cy = s->cy[j]; sp.r2 = r2j; have = true; }
+                    lox = nlox; hix = nhix; loz = nloz; hiz = nhiz;
+                    ++members;
+                }
+                ++sp.count;
+            }
+            if (!have) { sp.count = 0; return; }
+            sp.cxw = 0.5f * lox + 0.5f * hix;
+            sp.czw = 0.5f * loz + 0.5f * hiz;
+            double e = 0.0;
+            for (int j = i; j < i + sp.count; ++j)
+                if (filterable[j]) e = std::max({e, std::fabs(static_cast<double>(s->cx[j]) - sp.cxw), std::fabs(static_cast<double>(s->cz[j]) - sp.czw)});
+            sp.reach = std::max(e, std::sqrt(static_cast<double>(sp.r2)));
+            sp.cls = members >= 1 && std::isfinite(sp.cxw) && std::isfinite(sp.czw) && std::isfinite(sp.reach) && sp.reach > 0.0;
+        };
+        std::vector<Span> spans;
+        int covered = 0;
+        for (int i = 0; i < n;) {
+            Span sp;
+            class_run(i, sp);
+            if (sp.cls && (sp.count >= 8 || i + sp.count == n)) {
+                spans.push_back(sp);
+                covered += sp.count;
+                i += sp.count;
+                continue;
+            }
+            // no worthwhile class word starts here: this entry joins a kind-0 word
+            if (spans.empty() || spans.back().cls || spans.back().count == 32) spans.push_back({i, 0, false, 0.f, 0.f, 0.f, 0.f, 0.0});
+            ++spans.back().count;
+            ++i;
+        }
+        const int words = static_cast<int>(spans.size());
+        out.ltiles.assign(static_cast<size_t>(words) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        out.lwdesc.assign(static_cast<size_t>(words) * 3, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int w = 0; w < words; ++w) {
+            const Span& sp = spans[w];
+            const int base = sp.start;
+            uint32_t always = 0, valid = 0;
+            for (int i = base; i < base + sp.count; ++i) {
+                valid |= 0x80000000u >> (i - base);
+                if (!filterable[i]) always |= 0x80000000u >> (i - base);
+            }
+            int32_t kind = 0;
+            float sigw = 1.f, k0 = 0.f;
+            if (sp.cls) {
+                int ex = static_cast<int>(std::floor(std::log2(kLocalB / sp.reach)));
+                while (std::ldexp(sp.reach, ex) > kLocalB) --ex;
+                while (std::ldexp(sp.reach, ex + 1) <= kLocalB) ++ex;
+                if (ex >= -40 && ex <= 40) {
+                    const double sg = std::ldexp(1.0, ex);
+                    const double r2s = sg * sg * static_cast<double>(sp.r2);
+                    sigw = static_cast<float>(sg);
+                    k0 = std::nextafter(static_cast<float>(-(r2s + local_margin_const(r2s)) * (1.0 + 1e-6)), -inf);     // rounded down: more candidates
+                    kind = 1;
+                    uint16_t rows[32][16];
+                    for (int rho = 0; rho < 32; ++rho) {
+                        const int i = base + tile_row_sphere(rho);
+                        const bool live = i < base + sp.count && filterable[i] != 0;
+                        uint16_t parts[kQuadClassMonomials][2] = {};
+                        if (live) {
+                            const double x = sg * (static_cast<double>(s->cx[i]) - sp.cxw), z = sg * (static_cast<double>(s->cz[i]) - sp.czw);
+                            const double mono_c[kQuadClassMonomials] = {x * x, z * z, x * z, x, z};
+                            for (int m = 0; m < kQuadClassMonomials; ++m) {
+                                const double v = mono_c[m] * kQuadSphereScale;
+                                parts[m][0] = f16_rne(static_cast<float>(v));
+                                parts[m][1] = f16_rne(static_cast<float>(v - static_cast<double>(f16_value(parts[m][0]))));
+                            }
+                        }
+                        for (int k = 0; k < 16; ++k) {
+                            int mono, spart, rp;
+                            local_term(k, mono, spart, rp);
+                            rows[rho][k] = (live && mono >= 0) ? parts[mono][spart] : static_cast<uint16_t>(0);
+                        }
+                    }
+                    for (int l = 0; l < 64; ++l) {          // lane l: row l & 31, terms 8 (l >> 5) ... + 7
+                        uint16_t frag[8];
+                        for (int j = 0; j < 8; ++j) frag[j] = rows[l & 31][8 * (l >> 5) + j];
+                        std::memcpy(&out.ltiles[static_cast<size_t>(w) * 64 + l], frag, 16);
+                    }
+                    ++out.local_class_words;
+                } else {
+                    covered -= sp.count;
+                }
+            }
+            const int32_t start_kind = base * 2 + kind, count = sp.count;
+            float sk_f, count_f, always_f, valid_f;
+            std::memcpy(&sk_f, &start_kind, 4);
+            std::memcpy(&count_f, &count, 4);
+            std::memcpy(&always_f, &always, 4);
+            std::memcpy(&valid_f, &valid, 4);
+            out.lwdesc[3 * static_cast<size_t>(w)] = make_float4(sp.cxw, sp.cy, sp.czw, sigw);
+            out.lwdesc[3 * static_cast<size_t>(w) + 1] = make_float4(k0, sk_f, always_f, valid_f);
+            out.lwdesc[3 * static_cast<size_t>(w) + 2] = make_float4(count_f, 0.f, 0.f, 0.f);
+        }
+        out.local_words = words;
+        // worth it when nearly every sphere sits in a class word: a kind-0 word costs a full vector-ALU word fed by scalar loads
+        out.use_local = out.local_class_words > 0 && static_cast<double>(covered) >= 0.9 * n;
+    }
     if (compact) {
         // Matrix-pipe layout (SceneDev): per word a tile of f16 monomial parts as lane fragments and a descriptor.
         auto same_bits = [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; };

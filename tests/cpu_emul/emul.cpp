@@ -61,6 +61,7 @@ struct Emul {
 #define EMUL_FORCE_STAGED (RTK_LANES == 64)
 #endif
 static bool g_force_staged = EMUL_FORCE_STAGED;
+static bool g_local_frames = true;      // streamed scenes with local tiles use them (emul_local_frames(0): the staged vector-ALU walk)
 static bool use_lds_path(const Emul& e) { return e.compact; }
 
 template <bool LDS>
@@ -77,6 +78,11 @@ static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, 
     it.n = e.ps.n;
     it.lane = lane;
     it.stage = stage;
+    if (!LDS && e.ps.use_local && g_local_frames) {
+        it.ltiles = e.ps.ltiles.data();
+        it.lwdesc = e.ps.lwdesc.data();
+        it.lwords = e.ps.local_words;
+    }
     it.dbg_flags = dbg;
     return it;
 }
@@ -119,6 +125,9 @@ uint16_t emul_f16_rne(float v) { return f16_rne(v); }
 float emul_f16_value(uint16_t b) { return f16_value(b); }
 void emul_quad_term(int k, int n_mono, int* out3) { quad_term(k, n_mono, out3[0], out3[1], out3[2]); }
 void emul_force_staged(int on) { g_force_staged = on != 0; }
+void emul_local_frames(int on) { g_local_frames = on != 0; }
+// words of the scene with a tile in their own frame, and whether the streamed walk uses them
+int emul_local_words(void* h) { const Emul& e = *static_cast<Emul*>(h); return (!e.compact && e.ps.use_local && g_local_frames) ? e.ps.local_class_words : 0; }
 
 // filter bounds and per-sphere "filterable" flag as prepare_scene decided them
 void emul_scene_info(void* h, float* bounds8, uint8_t* filterable) {

@@ -26,6 +26,8 @@ def lib(lanes=1):
         l.emul_create.argtypes = [C.POINTER(rt.rtk_scene)]
         l.emul_destroy.argtypes = [vp]
         l.emul_class_words.argtypes = [vp]
+        l.emul_local_words.argtypes = [vp]
+        l.emul_local_frames.argtypes = [C.c_int]
         l.emul_scene_info.argtypes = [vp, vp, vp]
         l.emul_intersect.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int]
         l.emul_grid_info.argtypes = [vp, vp]
@@ -78,6 +80,10 @@ class Emul:
     def class_words(self) -> int:
         """Words of 32 spheres that got a 16-term class tile (shared cy and radius); 0 on the staged path."""
         return int(self._l.emul_class_words(self._h))
+
+    def local_words(self) -> int:
+        """Words with a tile in their own frame, when the scene streams through the matrix-pipe filter (else 0)."""
+        return int(self._l.emul_local_words(self._h))
 
     def grid_info(self):
         a = np.zeros(9, np.int64)
