@@ -251,7 +251,9 @@ def main():
                 counters = {}
         lay = ctx.scene_layout()
         n_class = 32 * lay["class_words"]
-        on_matrix_pipe = n_spheres <= 1024
+        # the filter runs on the matrix pipe for LDS-resident scenes and for streamed scenes whose words have tiles in their own
+        # frames (rtk_scene_layout: class words > 0); the staged vector-ALU walk is priced against the fp32 vector peak
+        on_matrix_pipe = n_spheres <= 1024 or lay["class_words"] > 0
         peak = ISSUE_BOUND_PEAK_TFLOPS if on_matrix_pipe else FP32_VECTOR_PEAK_TFLOPS
         filt_valu = 2.0 if on_matrix_pipe else 8.0                                      # vector instructions per ray-sphere filter test
         alg_bytes = args.width * args.height * 3 * (8 + 4) / world                       # per launch: one u64 accumulator + one fp32 sum per channel
@@ -273,6 +275,7 @@ def main():
                                    "frac_of_fp32_vector_peak is the measure of rounds 1-2, no longer an upper bound): " if on_matrix_pipe else "against the fp32 VECTOR peak: ") +
                                   "the kernel runs a conservative "
                                   "filter per test (" + ("one dot product of split-f16 monomials and coefficients on the matrix pipe, 2 x v_mfma_f32_32x32x16_f16 per class word of 32 spheres x 64 rays, then 2 fp32 vector FMAs"
+                                                         + ("" if n_spheres <= 1024 else "; streamed scene: per word the ray's linear coefficients and constant are rebuilt in the word's own frame, ~45 vector instructions")
                                                          if on_matrix_pipe else "8 fp32 vector instructions") +
                                   ") plus ~2 exact reference tests per ray; executed-instruction counts from counters: profiles/*_summary.md",
                          "filter_on_matrix_pipe": on_matrix_pipe,

@@ -30,7 +30,8 @@ using namespace rtk;
 
 // Dynamic LDS layout.  LDS-resident scene: [filt_lds] float4: A fragments of the words' f16 tiles, records of a short tail | [npad / 32] word
 // descriptors | [n] exact float4 | [4 waves][npad / 32][64] u32 candidate mask words (40 KiB per workgroup is what four
-// workgroups per CU allow: the stock scene needs 39.9).  Streamed scene: [4][kListCap][64] u16 candidate lists | [4][kStageSpheres] float4 staging chunks, one per wave.
+// workgroups per CU allow: the stock scene needs 39.9).  Streamed scene, per wave: [kListCap][64] u16 candidate list | [kStageSpheres] float4 staging chunk, or in the same memory [kEntryCap][64] (mask, index) entries of the word-local walk.
+constexpr size_t kStreamLdsPerWave = kEntryCap * kWave * sizeof(uint2) > kListCap * kWave * 2 + kStageSpheres * sizeof(float4) ? kEntryCap * kWave * sizeof(uint2) : kListCap * kWave * 2 + kStageSpheres * sizeof(float4);
 template <bool LDS>
 __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc, unsigned char* smem) {
     Intersector<LDS> it;
@@ -53,8 +54,11 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
     } else {
         it.filt = sc.filt;
         it.exact = sc.exact;
-        it.list = reinterpret_cast<uint16_t*>(p) + wave * (kListCap * kWave);
-        it.stage = reinterpret_cast<float4*>(p + kWavesPerBlock * kListCap * kWave * 2) + wave * kStageSpheres;
+        // per wave kStreamLdsPerWave bytes: the staged walk's list and chunk, or (same memory) the local walk's entries
+        unsigned char* mine = p + wave * kStreamLdsPerWave;
+        it.list = reinterpret_cast<uint16_t*>(mine);
+        it.stage = reinterpret_cast<float4*>(mine + kListCap * kWave * 2);
+        it.entries = reinterpret_cast<uint2*>(mine);
         it.ltiles = sc.ltiles;
         it.lwdesc = sc.lwdesc;
         it.lwords = sc.lwords;
@@ -68,7 +72,7 @@ __device__ __forceinline__ Intersector<LDS> make_intersector(const SceneDev& sc,
 
 static size_t lds_bytes(bool lds, const SceneDev& sc, int waves = kWavesPerBlock) {
     return lds ? static_cast<size_t>(sc.filt_lds + sc.npad / 32 + sc.n) * sizeof(float4) + static_cast<size_t>(waves) * (sc.npad / 32) * kWave * sizeof(uint32_t)
-               : kWavesPerBlock * kStageSpheres * sizeof(float4) + kWavesPerBlock * kListCap * kWave * 2;
+               : static_cast<size_t>(kWavesPerBlock) * kStreamLdsPerWave;
 }
 
 // GRID: closest hit through the uniform grid (rtk_context_set_accel) instead of the list walk.

@@ -35,6 +35,7 @@ constexpr int kTilePixels = 64;      // a tile / packet always holds 64 pixels
 constexpr int kBlockThreads = 4 * kWave;   // 4 waves per workgroup, one per SIMD
 constexpr int kWavesPerBlock = 4;
 constexpr int kListCap = 16;         // per-lane candidate list entries between flushes
+constexpr int kEntryCap = 16;        // streamed local walk: per-lane (mask word, first list index) entries between exact passes
 constexpr int kMaxLdsSpheres = 1024; // scenes up to this size are LDS-resident (32 B per sphere)
 
 // Relative widening of the filter's radius term: r^2 (1+2^-15)^2 (host, rtk_scene_prep.hpp); it absorbs the rounding of
@@ -126,6 +127,8 @@ struct FilterBounds {
     float rp2;       // r'max^2 = sigma^2 r_max2
     float t_quad;    // sqrt(2) c'^2 + r'max^2, rounded up
     float cls_cy2;   // cls_cy^2
+    // word-local frames (streamed scenes):
+    float lsig_max;  // the largest sigma_w of the scene's class words (0: none)
 };
 
 struct SceneDev {
@@ -160,7 +163,7 @@ struct SceneDev {
     // tile and two float4 of descriptor; null when the scene streams through the vector-ALU filter alone.
     // The list is cut into `lwords` words of at most 32 consecutive entries (rtk_scene_prep.hpp).
     const float4* ltiles = nullptr;  // [lwords][64]
-    const float4* lwdesc = nullptr;  // [lwords][3]: (frame centre x, y, z, sigma_w) (K0, 2 * first entry + kind, always bits, valid bits) (entries, -, -, -)
+    const float4* lwdesc = nullptr;  // [lwords][2]: (frame centre x, y, z, sigma_w) (K0, 2 * first entry + kind, always bits, valid bits: one per entry, from the top)
     int32_t lwords = 0;
 };
 constexpr int kShortTail = 8;
@@ -214,9 +217,10 @@ __host__ __device__ inline int tile_row_sphere(int rho) {
 //   => marg = 1.25 (sum) + 2^-21 = A0_w + kLocalA1 |p|^2 + kLocalA2 |v|^2,   K = |p|^2 - r~'^2 - marg.
 // |p| is clamped to 2 per component for the coefficients (|2 p| 2^13 must stay an f16 number): a clamped ray passes at
 // least 2 - sqrt(2) B > 1 from every centre of the word while r~'^2 + marg < B^2 + 0.1 for |v|^2 < kLocalSafeVV, so its
-// (wrong) sums are still positive; beyond kLocalSafeVV, or NaN, the lane takes every sphere of the word.
+// (wrong) sums are still positive; beyond kLocalSafeVV, or NaN, the word is judged as a whole (Intersector::closest_hit).
 constexpr float kLocalB = 0.625f;
 constexpr float kLocalSafeVV = 0x1p14f;
+constexpr int kLocalShortRun = 8;           // class runs of at most this many entries go into kind-0 words (vector ALUs, one batch of scalar loads)
 constexpr double kLocalReach = 100.0;      // a class word's centres stay within this many radii of its frame centre (host cut)
 constexpr float kLocalA1 = 1.25f * ((1.0f + 1.41422f * kLocalB) * kQuadEpsClass + 0.81f * 0x1p-19f);
 constexpr float kLocalA2 = 1.25f * 1.75f * 0x1p-19f;

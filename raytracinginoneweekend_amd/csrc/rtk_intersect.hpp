@@ -110,6 +110,7 @@ struct Intersector {
     const float4* ltiles = nullptr;   // !LDS: word-local tiles (SceneDev::ltiles) or null: the staged vector-ALU walk
     const float4* lwdesc = nullptr;   // !LDS: their descriptors
     int lwords = 0;                   // !LDS: words of the local cut
+    uint2* entries = nullptr;         // !LDS local walk: this wave's pending candidates in LDS: [kEntryCap][64] (mask word, first list index); shares the memory of list and stage
     FilterBounds fb;
     int n;
     int lane;
@@ -117,7 +118,7 @@ struct Intersector {
     uint8_t* dbg_flags = nullptr;   // emulation only: [n] set to 1 for every sphere the filter passes to the exact stage
 #endif
 #ifdef RTK_PROFILE_SECTIONS
-    mutable unsigned long long prof[2] = {0, 0};     // profile builds only (tools/build_variants.py name=-DRTK_PROFILE_SECTIONS=1): shader cycles in the filter, in the exact stage
+    mutable unsigned long long prof[4] = {0, 0, 0, 0};     // profile builds only (tools/build_variants.py name=-DRTK_PROFILE_SECTIONS=1): shader cycles in the filter, in the exact stage; streamed local walk: class words, kind-0 words, compaction (with early exact passes), final exact pass
 #endif
 
     // `list_base`: list entries are 16-bit offsets from it (the list is flushed before an offset could overflow).
@@ -228,6 +229,7 @@ struct Intersector {
                 for (int b = 0; b < 32; ++b)
                     if (cand & (0x80000000u >> b)) dbg_flags[base + b] = 1;
 #endif
+            if (!wave_any(cand != 0)) return;          // most words of a large scene have no candidate on any lane: one vote
             for (;;) {
                 while (wave_any(cand != 0 && cnt < kListCap)) {
                     RTK_STAT(lane, compact_iters);
@@ -556,7 +558,49 @@ struct Intersector {
         // ragged end) run the projection form on the vector ALUs with the spheres as scalar operands.
         auto scan_local = [&]() {
             const bool safe_ray = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
+            // |v|^2 = sigma_w^2 |o - c_w|^2 stays below kLocalSafeVV = 2^14 in every word while (|o| + c_max) sigma_max < 120: then the
+            // per-word check of far origins is skipped (one vote per pass instead of one per word)
+            const bool any_far = wave_any(active && !((o_len + fb.c_max) * fb.lsig_max < 120.0f));
             const int words = lwords;
+            // Pending candidates: one (mask word, first list index) entry per word that has any, written without a vote
+            // (every lane writes its slot, only lanes with a candidate advance); the exact stage runs when a lane could run
+            // out of slots within the next eight words, and at the end.  Ascending list order throughout: the tie rule.
+            int ecnt = 0;
+            auto push = [&](int base, uint32_t cand) {
+#ifdef RTK_HOST_EMULATION
+                if (dbg_flags)
+                    for (int b = 0; b < 32; ++b)
+                        if (cand & (0x80000000u >> b)) dbg_flags[base + b] = 1;
+#endif
+                entries[ecnt * kWave + lane] = make_uint2(cand, static_cast<uint32_t>(base));
+                ecnt += cand != 0 ? 1 : 0;
+            };
+            auto drain = [&]() {
+                uint32_t m = 0;
+                int wb = 0, e = 0;
+                while (wave_any(m != 0 || e < ecnt)) {
+                    RTK_STAT(lane, flush_iters);
+                    if (m == 0 && e < ecnt) {
+                        const uint2 en = entries[e * kWave + lane];
+                        m = en.x;
+                        wb = static_cast<int>(en.y);
+                        ++e;
+                    }
+                    n_exact += static_cast<uint32_t>(__popcll(ballot(m != 0)));
+                    if (m != 0) {
+                        const int pos = __clz(static_cast<int>(m));
+                        m &= ~(0x80000000u >> pos);
+                        const int j = wb + pos;
+                        const float4 s = exact[j];
+                        float root;
+                        if (sphere_root_exact(r, a, s, t_min, closest, root)) {
+                            closest = root;
+                            best = j;
+                        }
+                    }
+                }
+                ecnt = 0;
+            };
             // the quadratic coefficients: the ray's alone
             const float qc[3] = {fmaf(dy, dy, dz * dz) * kQuadRayScale, fmaf(dx, dx, dy * dy) * kQuadRayScale, -2.0f * dx * dz * kQuadRayScale};
             uint16_t qp[3][2];
@@ -594,21 +638,35 @@ struct Intersector {
             }
             float4 av_next = ltiles[lane];
 #endif
+            // the next word's descriptor is requested before this word's work, its tile fragment likewise
+            auto n0 = desc[0], n1 = desc[1];
             for (int w = 0; w < words; ++w) {
-                const auto d0 = desc[3 * w], d1 = desc[3 * w + 1], d2 = desc[3 * w + 2];
+                const auto d0 = n0, d1 = n1;
 #ifndef RTK_HOST_EMULATION
+                // scalar loads return out of order, so the only wait there is drains them all: wait for this word's descriptor
+                // BEFORE the next one is requested, or the wait at its first use would take the new request with it
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+#endif
+                {
+                    const int wn = w + 1 < words ? w + 1 : w;
+                    n0 = desc[2 * wn];
+                    n1 = desc[2 * wn + 1];
+                }
+#ifndef RTK_HOST_EMULATION
+                __builtin_amdgcn_sched_barrier(0);
                 const float4 av = av_next;
                 av_next = ltiles[(w + 1 < words ? w + 1 : w) * 64 + lane];
-                const int start_kind = __builtin_amdgcn_readfirstlane(__float_as_int(d1.y)), count = __builtin_amdgcn_readfirstlane(__float_as_int(d2.x));
+                const int start_kind = __builtin_amdgcn_readfirstlane(__float_as_int(d1.y));
 #else
-                const int start_kind = __float_as_int(d1.y), count = __float_as_int(d2.x);
+                const int start_kind = __float_as_int(d1.y);
 #endif
+                const int count = __builtin_popcount(__float_as_uint(d1.w));
                 const bool cls = (start_kind & 1) != 0;
                 const int base = start_kind >> 1;
-                if (base - list_base > 65535 - 64) {     // scenes beyond 64k spheres: re-base the 16-bit list offsets
-                    flush(r, a, t_min, list_base, cnt, closest, best, n_exact);
-                    list_base = base;
-                }
+#ifdef RTK_PROFILE_SECTIONS
+                const unsigned long long pw0 = __builtin_readcyclecounter();
+#endif
                 const uint32_t always = __float_as_uint(d1.z), valid = __float_as_uint(d1.w);
                 uint32_t m = 0;
                 bool judged = safe;
@@ -620,9 +678,10 @@ struct Intersector {
                     const float px = fmaf(-sd, dx, vx), py = fmaf(-sd, dy, vy), pz = fmaf(-sd, dz, vz);
                     const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
                     const float vv = fmaf(sd, sd, pp);
-                    judged = safe_ray && (vv < kLocalSafeVV);
+                    judged = safe_ray;
                     // constant: (|p|^2 - r~'^2 - marg) 2^27, pushed away from zero so that it is a multiple of 2^-48, then times -2^48
-                    float ks = fmaf(pp, 1.0f - kLocalA1, fmaf(vv, -kLocalA2, d1.x)) * (kQuadSphereScale * kQuadRayScale);
+                    const float kraw = fmaf(pp, 1.0f - kLocalA1, fmaf(vv, -kLocalA2, d1.x));
+                    float ks = kraw * (kQuadSphereScale * kQuadRayScale);
                     ks = fabsf(ks) < 0x1p-24f ? -0x1p-24f : ks;
                     const float kc = ks * -0x1p48f;
                     // linear coefficients -2 p 2^13 from the clamped p, in two f16 parts
@@ -671,20 +730,49 @@ struct Intersector {
                     mfma_pair(t0, t1, a0, b0, b1);
                     m = mfma_join(mfma_bits16(t0, __uint_as_float(sw[0])), mfma_bits16(t1, __uint_as_float(sw[1])));
 #endif
+                    // Origins so far from the word that the reference's rounding noise (2^-19 |v|^2) rivals the squares the dot product
+                    // is made of (a bounce off the far side of the ground sphere, seen from a short word's fine frame): the clamped
+                    // sums prove nothing there.  thr = |p|^2 - K is everything a centre's squared distance from the line may be
+                    // for the reference to accept it; no centre is farther than sqrt(2) B from the frame's: the whole word is out
+                    // when |p| > sqrt(2) B + sqrt(thr) (sqrt(x) <= (x + 1) / 2), else every sphere of it is a candidate.
+                    if (any_far) {          // wave-uniform
+                        const float rf = fmaf(pp - kraw, 0.5f, 0.5f + 1.41422f * kLocalB);
+                        const bool out = pp * (1.0f - 0x1p-10f) > rf * rf;
+                        if (!(vv < kLocalSafeVV)) m = out ? 0u : 0xFFFFFFFFu;          // also for NaN
+                    }
                     m |= always;
                     RTK_STAT(lane, class_words);
                 } else {
-#pragma unroll 8
-                    for (int i = 0; i < count; ++i) {
-                        const auto sp = src[base + i];
-                        filter_one(f, sp.x, sp.y, sp.z, sp.w, m);
+                    // batches of eight spheres, each requested whole (two s_load_dwordx16) and waited for once; entries past
+                    // the word's end are read (the array is padded) and masked by `valid`
+                    for (int b8 = 0; b8 < count; b8 += 8) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const auto sp = src[base + b8 + i];
+                            filter_one(f, sp.x, sp.y, sp.z, sp.w, m);
+                        }
                     }
-                    m <<= (32 - count);
+                    m <<= (32 - ((count + 7) & ~7));
                 }
                 RTK_STAT(lane, filter_words);
                 const uint32_t cand = (judged ? m : 0xFFFFFFFFu) & valid;
-                emit(base, active ? cand : 0u);
+#ifdef RTK_PROFILE_SECTIONS
+                const unsigned long long pw1 = __builtin_readcyclecounter();
+                prof[cls ? 0 : 1] += pw1 - pw0;
+#endif
+                push(base, active ? cand : 0u);
+                if ((w & 7) == 7 && wave_any(ecnt > kEntryCap - 8)) drain();
+#ifdef RTK_PROFILE_SECTIONS
+                prof[2] += __builtin_readcyclecounter() - pw1;
+#endif
             }
+#ifdef RTK_PROFILE_SECTIONS
+            const unsigned long long pf0 = __builtin_readcyclecounter();
+#endif
+            drain();
+#ifdef RTK_PROFILE_SECTIONS
+            prof[3] += __builtin_readcyclecounter() - pf0;
+#endif
         };
         if (!LDS) {
             // Scenes too large to live in LDS: the wave streams the list through a private LDS chunk — one coalesced

@@ -238,9 +238,10 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
     // profile builds only: where this wave's shader cycles went (wall cycles of the wave: its SIMD interleaves it with the others)
     if (lane == 0 && blockIdx.x < 3) {
         const unsigned long long total = __builtin_readcyclecounter() - prof_begin;
-        printf("wave %d.%d: passes %u  cycles/pass: total %.0f  filter %.0f  exact stage %.0f  rest %.0f\n", static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x / kWave),
+        printf("wave %d.%d: passes %u  cycles/pass: total %.0f  filter %.0f  exact stage %.0f  (streamed local walk: compaction %.0f  final exact pass %.0f)  rest %.0f\n", static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x / kWave),
                wave_passes, static_cast<double>(total) / wave_passes, static_cast<double>(isect.prof[0]) / wave_passes, static_cast<double>(isect.prof[1]) / wave_passes,
-               static_cast<double>(total - isect.prof[0] - isect.prof[1]) / wave_passes);
+               static_cast<double>(isect.prof[2]) / wave_passes, static_cast<double>(isect.prof[3]) / wave_passes,
+               static_cast<double>(total - isect.prof[0] - isect.prof[1] - isect.prof[2] - isect.prof[3]) / wave_passes);
     }
 #endif
     if (lane == 0) {

@@ -38,7 +38,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
     out.n = n;
     out.npad = npad;
     std::vector<float4>&filt = out.filt, &exact = out.exact, &m0 = out.m0, &m1 = out.m1;
-    filt.assign(npad, make_float4(0.f, 0.f, 0.f, 0.f));
+    filt.assign(npad + 8, make_float4(0.f, 0.f, 0.f, -std::numeric_limits<float>::infinity()));      // 8 inert entries past the end: kind-0 words of the local walk read whole batches of eight
     exact.assign(npad, make_float4(0.f, 0.f, 0.f, 0.f));
     m0.assign(n, make_float4(0.f, 0.f, 0.f, 0.f));
     m1.assign(n, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -69,7 +69,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         volatile float rr_v = s->radius[i] * s->radius[i];
         return static_cast<float>(rr_v) * kFilterScaleSq;
     };
-    FilterBounds fb = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, kQuadEpsClass, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    FilterBounds fb = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, kQuadEpsClass, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (!order.empty()) {
         fb.r_min = inf;
         for (int i : order) {
@@ -148,7 +148,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         for (int i = 0; i < n;) {
             Span sp;
             class_run(i, sp);
-            if (sp.cls && (sp.count >= 8 || i + sp.count == n)) {
+            if (sp.cls && (sp.count > kLocalShortRun || i + sp.count == n)) {          // a class word costs ~500 SIMD cycles whatever it holds; a few spheres are cheaper on the vector ALUs
                 spans.push_back(sp);
                 covered += sp.count;
                 i += sp.count;
@@ -161,7 +161,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         }
         const int words = static_cast<int>(spans.size());
         out.ltiles.assign(static_cast<size_t>(words) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
-        out.lwdesc.assign(static_cast<size_t>(words) * 3, make_float4(0.f, 0.f, 0.f, 0.f));
+        out.lwdesc.assign(static_cast<size_t>(words) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
         for (int w = 0; w < words; ++w) {
             const Span& sp = spans[w];
             const int base = sp.start;
@@ -180,6 +180,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
                     const double sg = std::ldexp(1.0, ex);
                     const double r2s = sg * sg * static_cast<double>(sp.r2);
                     sigw = static_cast<float>(sg);
+                    out.fb.lsig_max = std::fmax(out.fb.lsig_max, sigw);
                     k0 = std::nextafter(static_cast<float>(-(r2s + local_margin_const(r2s)) * (1.0 + 1e-6)), -inf);     // rounded down: more candidates
                     kind = 1;
                     uint16_t rows[32][16];
@@ -212,19 +213,18 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
                     covered -= sp.count;
                 }
             }
-            const int32_t start_kind = base * 2 + kind, count = sp.count;
-            float sk_f, count_f, always_f, valid_f;
+            const int32_t start_kind = base * 2 + kind;          // the word's entries: the set bits of `valid` (a run from the top bit)
+            float sk_f, always_f, valid_f;
             std::memcpy(&sk_f, &start_kind, 4);
-            std::memcpy(&count_f, &count, 4);
             std::memcpy(&always_f, &always, 4);
             std::memcpy(&valid_f, &valid, 4);
-            out.lwdesc[3 * static_cast<size_t>(w)] = make_float4(sp.cxw, sp.cy, sp.czw, sigw);
-            out.lwdesc[3 * static_cast<size_t>(w) + 1] = make_float4(k0, sk_f, always_f, valid_f);
-            out.lwdesc[3 * static_cast<size_t>(w) + 2] = make_float4(count_f, 0.f, 0.f, 0.f);
+            out.lwdesc[2 * static_cast<size_t>(w)] = make_float4(sp.cxw, sp.cy, sp.czw, sigw);
+            out.lwdesc[2 * static_cast<size_t>(w) + 1] = make_float4(k0, sk_f, always_f, valid_f);
         }
         out.local_words = words;
-        // worth it when nearly every sphere sits in a class word: a kind-0 word costs a full vector-ALU word fed by scalar loads
-        out.use_local = out.local_class_words > 0 && static_cast<double>(covered) >= 0.9 * n;
+        // worth it when nearly every sphere sits in a class word (a kind-0 word costs a full vector-ALU word fed by scalar loads)
+        // and the words are reasonably full (a word costs the same whether it holds 32 spheres or one)
+        out.use_local = out.local_class_words > 0 && static_cast<double>(covered) >= 0.9 * n && words <= 2 * ((n + 31) / 32);
     }
     if (compact) {
         // Matrix-pipe layout (SceneDev): per word a tile of f16 monomial parts as lane fragments and a descriptor.

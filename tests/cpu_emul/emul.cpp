@@ -66,6 +66,7 @@ static bool use_lds_path(const Emul& e) { return e.compact; }
 
 template <bool LDS>
 static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, int lane = 0, float4* stage = nullptr, uint32_t* masks = nullptr) {
+    static thread_local std::vector<uint2> entries_buf(static_cast<size_t>(kEntryCap) * kWave);          // one wave at a time per thread
     Intersector<LDS> it;
     it.filt = e.ps.filt.data();
     if (LDS) {
@@ -82,6 +83,7 @@ static Intersector<LDS> make_isect(const Emul& e, uint16_t* list, uint8_t* dbg, 
         it.ltiles = e.ps.ltiles.data();
         it.lwdesc = e.ps.lwdesc.data();
         it.lwords = e.ps.local_words;
+        it.entries = entries_buf.data();
     }
     it.dbg_flags = dbg;
     return it;

@@ -176,6 +176,64 @@ def test_large_scene_config4():
     check(s, rays, noises=(3,))
 
 
+# ---- scenes beyond LDS: the matrix-pipe filter in word-local frames (rtk_device.hpp local_term) ----------
+def test_local_frames_cut_and_candidate_count():
+    """scaled_scene(k=30): 3601 spheres in rows of 60 -> the list is cut at every row end (a word must not wrap to the next
+    row: its frame would be wider than kLocalReach radii), all but the three large spheres sit in class words, and the
+    filter passes about as many candidates as the vector-ALU projection form it replaces."""
+    s = rt.scaled_scene(k=30)
+    assert len(s["cx"]) > 1024
+    e = Emul(s)
+    assert e.local_words() >= 120                      # 60 rows x (32 + 28)
+    rng = np.random.default_rng(2)
+    m = 2000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-30, 30, m); rays[:, 1] = rng.uniform(0.01, 3, m); rays[:, 2] = rng.uniform(-30, 30, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.2
+    over = check(s, rays)
+    emul.lib().emul_local_frames(0)
+    try:
+        assert Emul(s).local_words() == 0
+        over_staged = check(s, rays)
+    finally:
+        emul.lib().emul_local_frames(1)
+    assert over < 1.25 * over_staged + 0.1, (over, over_staged)
+
+
+@pytest.mark.parametrize("lo,hi", [(0.01, 1), (1, 30), (30, 300), (300, 3000), (3000, 1e5), (1e5, 1e8)])
+def test_local_frames_tangent_rays_at_every_distance(lo, hi):
+    """Grazing rays from every distance, hardware noise on: near origins are judged by the dot product, origins beyond
+    |v|^2 = 2^14 in a word's own units (a bounce off the far side of the ground sphere) by the word as a whole."""
+    s = rt.scaled_scene(k=20)
+    rng = np.random.default_rng(int(lo * 100) + 7)
+    for eps in (0.0, 1e-6, 1e-3, 0.3):
+        check(s, tangent_rays(rng, s, 800, lo, hi, eps, first=1))
+
+
+def test_local_frames_far_origins_do_not_take_every_sphere():
+    """A ray that starts ~1000 units away (the far side of the ground sphere) must not turn the short words at the row ends
+    into candidates wholesale: that was 400 exact tests for each such ray of the 10 001-sphere scene."""
+    s = rt.scaled_scene(k=20)
+    rng = np.random.default_rng(8)
+    m = 400
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-900, 900, m); rays[:, 1] = rng.uniform(-1500, -200, m); rays[:, 2] = rng.uniform(-900, 900, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3))
+    e = Emul(s)
+    hit, idx, t, flags = e.intersect(rays, want_flags=True, ulp_noise=3)
+    o = po.Oracle(); o.set_scene(s)
+    dp = o.disc_pass(rays)
+    assert int(((dp == 1) & (flags == 0)).sum()) == 0
+    assert flags.sum() < 3 * dp.sum() + 4 * m, (flags.sum(), dp.sum())
+
+
+def test_local_frames_mixed_scene_keeps_the_staged_walk():
+    """Mixed radii: almost no word is a class word, the scene streams through the vector-ALU filter as before."""
+    rng = np.random.default_rng(12)
+    s = _odd_scene(rng, 1500)
+    assert Emul(s).local_words() == 0
+
+
 def test_candidate_lists_overflow_path(stock_scene_golden):
     """Degenerate (unsafe) rays make all 484 spheres candidates: the 16-entry lane list is flushed 31 times and
     the running closest / NaN behaviour must survive the early exact passes."""

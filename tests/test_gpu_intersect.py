@@ -130,6 +130,58 @@ def test_large_scene_config4_vs_oracle():
     ctx.close()
 
 
+def test_word_local_frames_vs_staged_walk_and_oracle(monkeypatch):
+    """Scenes beyond LDS whose words are class words run the matrix-pipe filter in word-local frames; with
+    RTK_NO_LOCAL_FRAMES set the same scene streams through the vector-ALU filter.  Both must give the reference's hits bit
+    for bit — also for origins hundreds of units away, where a word is judged as a whole — and the same image."""
+    from test_emul_intersect import tangent_rays
+    s = rt.scaled_scene(k=50)
+    o = po.Oracle(); o.set_scene(s)
+    rng = np.random.default_rng(19)
+    m = 40000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-50, 50, m); rays[:, 1] = rng.uniform(0.01, 4, m); rays[:, 2] = rng.uniform(-50, 50, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.2
+    rays[::7, 0:3] *= rng.uniform(5, 60, (len(rays[::7]), 1)).astype(np.float32)          # far origins
+    rays[::7, 1] -= 300.0                                                                  # ... below the horizon of the ground sphere
+    rays[::97, 3] = np.nan
+    rays = np.concatenate([rays, tangent_rays(rng, s, 8000, 0.5, 3000, 1e-5, first=1)])
+    want = o.intersect(rays)
+    results = {}
+    for no_local in (False, True):
+        if no_local:
+            monkeypatch.setenv("RTK_NO_LOCAL_FRAMES", "1")
+        else:
+            monkeypatch.delenv("RTK_NO_LOCAL_FRAMES", raising=False)
+        ctx = rt.Context(0); ctx.set_scene(s)
+        lay = ctx.scene_layout()
+        assert not lay["lds_resident"]
+        assert (lay["class_words"] == 0) if no_local else (lay["class_words"] >= 300)
+        check(ctx.intersect(rays), *want)
+        img, st = ctx.render(rt.stock_camera(1.5), 96, 64, 8, 50, seed=4)
+        results[no_local] = (img, st)
+        ctx.close()
+    (a, sa), (b, sb) = results[False], results[True]
+    assert np.array_equal(bits(a), bits(b)) and sa["rays"] == sb["rays"]
+    assert sa["sphere_tests"] < 1.5 * sb["sphere_tests"]          # about as many exact tests as the projection form needs
+
+
+def test_word_local_frames_100k_spheres_vs_oracle():
+    """BASELINE.json configs[3] at its upper end: 99 857 spheres, rows of 316 cut into words of 32 and a rest."""
+    s = rt.scaled_scene(k=158)
+    assert len(s["cx"]) > 99000
+    o = po.Oracle(); o.set_scene(s)
+    ctx = rt.Context(0); ctx.set_scene(s)
+    assert ctx.scene_layout()["class_words"] >= 3100
+    rng = np.random.default_rng(23)
+    m = 4000
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0] = rng.uniform(-158, 158, m); rays[:, 1] = rng.uniform(0.01, 4, m); rays[:, 2] = rng.uniform(-158, 158, m)
+    rays[:, 3:6] = rng.normal(size=(m, 3)); rays[:, 4] *= 0.1
+    check(ctx.intersect(rays), *o.intersect(rays))
+    ctx.close()
+
+
 def test_errors(gpu_ctx):
     ctx = rt.Context(0)
     with pytest.raises(rt.RtkError, match="rtk_set_scene first"):
