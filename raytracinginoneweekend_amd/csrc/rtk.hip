@@ -544,6 +544,8 @@ int rtk_set_scene(rtk_context* c, const rtk_scene* s) {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false>, kBlockThreads, shm));
         }
         c->blocks_per_cu[l] = nb > 0 ? nb : 1;
+        if (const char* e = std::getenv("RTK_EXP_BLOCKS_PER_CU"))          // occupancy studies only (tools/): fewer resident workgroups per CU
+            if (std::atoi(e) > 0 && std::atoi(e) < c->blocks_per_cu[l]) c->blocks_per_cu[l] = std::atoi(e);
     }
     return RTK_OK;
 }

@@ -163,7 +163,7 @@ struct SceneDev {
     // tile and two float4 of descriptor; null when the scene streams through the vector-ALU filter alone.
     // The list is cut into `lwords` words of at most 32 consecutive entries (rtk_scene_prep.hpp).
     const float4* ltiles = nullptr;  // [lwords][64]
-    const float4* lwdesc = nullptr;  // [lwords][2]: (frame centre x, y, z, sigma_w) (K0, 2 * first entry + kind, always bits, valid bits: one per entry, from the top)
+    const float4* lwdesc = nullptr;  // [lwords][3]: (frame centre x, y, z, 2 / sigma_w) (k0, 2 * first entry + kind, always bits, valid bits: one per entry, from the top) (s1, -2 sigma_w 2^13, sigma_w^2, -): rtk_scene_prep.hpp
     int32_t lwords = 0;
 };
 constexpr int kShortTail = 8;
@@ -224,6 +224,7 @@ constexpr int kLocalShortRun = 8;           // class runs of at most this many e
 constexpr double kLocalReach = 100.0;      // a class word's centres stay within this many radii of its frame centre (host cut)
 constexpr float kLocalA1 = 1.25f * ((1.0f + 1.41422f * kLocalB) * kQuadEpsClass + 0.81f * 0x1p-19f);
 constexpr float kLocalA2 = 1.25f * 1.75f * 0x1p-19f;
+constexpr float kLocalRatio = -kLocalA2 / (1.0f - kLocalA1);      // K = (1 - A1) (|p|^2 + ratio |v|^2) - r~'^2 - A0_w
 // the word's part of the margin, given its scaled widened radius^2 (host, rounded up by the caller)
 inline double local_margin_const(double r2s) {
     const double B = kLocalB;

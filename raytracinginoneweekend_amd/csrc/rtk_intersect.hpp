@@ -560,7 +560,14 @@ struct Intersector {
             const bool safe_ray = (fabsf(r.o.x) < big) && (fabsf(r.o.y) < big) && (fabsf(r.o.z) < big) && (a > 0x1p-80f) && (a < 0x1p80f);
             // |v|^2 = sigma_w^2 |o - c_w|^2 stays below kLocalSafeVV = 2^14 in every word while (|o| + c_max) sigma_max < 120: then the
             // per-word check of far origins is skipped (one vote per pass instead of one per word)
+#ifdef RTK_HOST_EMULATION
             const bool any_far = wave_any(active && !((o_len + fb.c_max) * fb.lsig_max < 120.0f));
+#else
+            // (through readfirstlane: a scalar the compiler branches on, instead of folding it into the per-lane condition
+            // below and issuing that block under an empty EXEC for every word)
+            int any_far = __builtin_amdgcn_readfirstlane(wave_any(active && !((o_len + fb.c_max) * fb.lsig_max < 120.0f)) ? 1 : 0);
+            asm volatile("" : "+s"(any_far));
+#endif
             const int words = lwords;
             // Pending candidates: one (mask word, first list index) entry per word that has any, written without a vote
             // (every lane writes its slot, only lanes with a candidate advance); the exact stage runs when a lane could run
@@ -639,9 +646,11 @@ struct Intersector {
             float4 av_next = ltiles[lane];
 #endif
             // the next word's descriptor is requested before this word's work, its tile fragment likewise
-            auto n0 = desc[0], n1 = desc[1];
+            auto n0 = desc[0], n1 = desc[1], n2 = desc[2];
+            // lanes the filter cannot judge take every sphere of a word, inactive lanes none: masks, set once per pass
+            const uint32_t force_class = safe_ray ? 0u : 0xFFFFFFFFu, force_kind0 = safe ? 0u : 0xFFFFFFFFu, keep = active ? 0xFFFFFFFFu : 0u;
             for (int w = 0; w < words; ++w) {
-                const auto d0 = n0, d1 = n1;
+                const auto d0 = n0, d1 = n1, d2 = n2;
 #ifndef RTK_HOST_EMULATION
                 // scalar loads return out of order, so the only wait there is drains them all: wait for this word's descriptor
                 // BEFORE the next one is requested, or the wait at its first use would take the new request with it
@@ -650,8 +659,9 @@ struct Intersector {
 #endif
                 {
                     const int wn = w + 1 < words ? w + 1 : w;
-                    n0 = desc[2 * wn];
-                    n1 = desc[2 * wn + 1];
+                    n0 = desc[3 * wn];
+                    n1 = desc[3 * wn + 1];
+                    n2 = desc[3 * wn + 2];
                 }
 #ifndef RTK_HOST_EMULATION
                 __builtin_amdgcn_sched_barrier(0);
@@ -669,29 +679,45 @@ struct Intersector {
 #endif
                 const uint32_t always = __float_as_uint(d1.z), valid = __float_as_uint(d1.w);
                 uint32_t m = 0;
-                bool judged = safe;
                 if (cls) {
-                    // the ray in the word's frame
-                    const float sg = d0.w;
-                    const float vx = (r.o.x - d0.x) * sg, vy = (r.o.y - d0.y) * sg, vz = (r.o.z - d0.z) * sg;
+                    // the ray in the word's frame, UNSCALED (sigma_w and the fixed-point scales are folded into the word's constants)
+                    const float vx = r.o.x - d0.x, vy = r.o.y - d0.y, vz = r.o.z - d0.z;
                     const float sd = fmaf(vz, dz, fmaf(vy, dy, vx * dx));
                     const float px = fmaf(-sd, dx, vx), py = fmaf(-sd, dy, vy), pz = fmaf(-sd, dz, vz);
                     const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
                     const float vv = fmaf(sd, sd, pp);
-                    judged = safe_ray;
-                    // constant: (|p|^2 - r~'^2 - marg) 2^27, pushed away from zero so that it is a multiple of 2^-48, then times -2^48
-                    const float kraw = fmaf(pp, 1.0f - kLocalA1, fmaf(vv, -kLocalA2, d1.x));
-                    float ks = kraw * (kQuadSphereScale * kQuadRayScale);
-                    ks = fabsf(ks) < 0x1p-24f ? -0x1p-24f : ks;
-                    const float kc = ks * -0x1p48f;
-                    // linear coefficients -2 p 2^13 from the clamped p, in two f16 parts
-                    const float lx = fminf(fmaxf(px, -2.0f), 2.0f) * (-2.0f * kQuadRayScale), lz = fminf(fmaxf(pz, -2.0f), 2.0f) * (-2.0f * kQuadRayScale);
+                    // constant: -2^48 2^27 (|p|^2 - r~'^2 - marg) in scaled units; pushed away from zero so that it is an integer
+                    float kc = fmaf(fmaf(vv, kLocalRatio, pp), d2.x, d1.x);
+                    kc = fabsf(kc) < 0x1p24f ? 0x1p24f : kc;
+                    // linear coefficients -2 sigma p 2^13 from p clamped to 2 scaled units, in two f16 parts
+                    const float lim = d0.w;
+#ifdef RTK_HOST_EMULATION
+                    const float lx = fminf(fmaxf(px, -lim), lim) * d2.y, lz = fminf(fmaxf(pz, -lim), lim) * d2.y;
+#else
+                    const float lx = __builtin_amdgcn_fmed3f(px, -lim, lim) * d2.y, lz = __builtin_amdgcn_fmed3f(pz, -lim, lim) * d2.y;
+#endif
+#ifdef RTK_HOST_EMULATION
                     uint16_t lp[2][2];
                     f16_split2(lx, lp[0]);
                     f16_split2(lz, lp[1]);
                     lo[2] = term(4, lp) | (term(5, lp) << 16);
                     lo[3] = term(6, lp) | (term(7, lp) << 16);
                     hi[3] = term(14, lp) | (term(15, lp) << 16);
+#else
+                    {
+                        // the same split with packed conversions: H = (hi part of lx, of lz), L = the parts of the (exact) residuals;
+                        // local_term puts them at lo[2] = (lx hi, lx lo), lo[3] = (lx hi, lz hi) = H, hi[3] = (lz hi, lz lo)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 l2 = {lx, lz};
+                        const f16x2 H = __builtin_convertvector(l2, f16x2);
+                        const f16x2 L = __builtin_convertvector(l2 - __builtin_convertvector(H, f32x2), f16x2);
+                        const uint32_t hu = __builtin_bit_cast(uint32_t, H), lu = __builtin_bit_cast(uint32_t, L);
+                        lo[2] = __builtin_amdgcn_perm(lu, hu, 0x05040100u);
+                        lo[3] = hu;
+                        hi[3] = __builtin_amdgcn_perm(lu, hu, 0x07060302u);
+                    }
+#endif
 #ifdef RTK_HOST_EMULATION
                     const float4* tile = ltiles + static_cast<size_t>(w) * 64;
                     uint16_t vb[16];
@@ -736,11 +762,13 @@ struct Intersector {
                     // for the reference to accept it; no centre is farther than sqrt(2) B from the frame's: the whole word is out
                     // when |p| > sqrt(2) B + sqrt(thr) (sqrt(x) <= (x + 1) / 2), else every sphere of it is a candidate.
                     if (any_far) {          // wave-uniform
-                        const float rf = fmaf(pp - kraw, 0.5f, 0.5f + 1.41422f * kLocalB);
-                        const bool out = pp * (1.0f - 0x1p-10f) > rf * rf;
-                        if (!(vv < kLocalSafeVV)) m = out ? 0u : 0xFFFFFFFFu;          // also for NaN
+                        const float pps = pp * d2.z, vvs = vv * d2.z;                                      // in scaled units
+                        const float kraw = fmaf(fmaf(vv, kLocalRatio, pp), d2.x, d1.x) * -0x1p-75f;          // K, before the push away from zero
+                        const float rf = fmaf(pps - kraw, 0.5f, 0.5f + 1.41422f * kLocalB);
+                        const bool out = pps * (1.0f - 0x1p-10f) > rf * rf;
+                        m = (vvs < kLocalSafeVV) ? m : (out ? 0u : 0xFFFFFFFFu);          // the second arm also for NaN
                     }
-                    m |= always;
+                    m = ((m | always | force_class) & valid) & keep;
                     RTK_STAT(lane, class_words);
                 } else {
                     // batches of eight spheres, each requested whole (two s_load_dwordx16) and waited for once; entries past
@@ -753,14 +781,15 @@ struct Intersector {
                         }
                     }
                     m <<= (32 - ((count + 7) & ~7));
+                    m = ((m | force_kind0) & valid) & keep;
                 }
                 RTK_STAT(lane, filter_words);
-                const uint32_t cand = (judged ? m : 0xFFFFFFFFu) & valid;
+                const uint32_t cand = m;
 #ifdef RTK_PROFILE_SECTIONS
                 const unsigned long long pw1 = __builtin_readcyclecounter();
                 prof[cls ? 0 : 1] += pw1 - pw0;
 #endif
-                push(base, active ? cand : 0u);
+                push(base, cand);
                 if ((w & 7) == 7 && wave_any(ecnt > kEntryCap - 8)) drain();
 #ifdef RTK_PROFILE_SECTIONS
                 prof[2] += __builtin_readcyclecounter() - pw1;

@@ -161,7 +161,7 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
         }
         const int words = static_cast<int>(spans.size());
         out.ltiles.assign(static_cast<size_t>(words) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
-        out.lwdesc.assign(static_cast<size_t>(words) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        out.lwdesc.assign(static_cast<size_t>(words) * 3, make_float4(0.f, 0.f, 0.f, 0.f));
         for (int w = 0; w < words; ++w) {
             const Span& sp = spans[w];
             const int base = sp.start;
@@ -172,16 +172,24 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             }
             int32_t kind = 0;
             float sigw = 1.f, k0 = 0.f;
+            float4 scaled = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sp.cls) {
                 int ex = static_cast<int>(std::floor(std::log2(kLocalB / sp.reach)));
                 while (std::ldexp(sp.reach, ex) > kLocalB) --ex;
                 while (std::ldexp(sp.reach, ex + 1) <= kLocalB) ++ex;
-                if (ex >= -40 && ex <= 40) {
+                if (ex >= -20 && ex <= 20) {
                     const double sg = std::ldexp(1.0, ex);
                     const double r2s = sg * sg * static_cast<double>(sp.r2);
                     sigw = static_cast<float>(sg);
                     out.fb.lsig_max = std::fmax(out.fb.lsig_max, sigw);
-                    k0 = std::nextafter(static_cast<float>(-(r2s + local_margin_const(r2s)) * (1.0 + 1e-6)), -inf);     // rounded down: more candidates
+                    // The kernel works with the UNSCALED v = o - c_w and folds sigma_w (a power of two: exact) and the fixed-point
+                    // scales into per-word constants:  kc = -2^48 2^27 K = (|p|^2 + ratio |v|^2) s1 + k0,
+                    //   s1 = -2^75 (1 - A1) sigma^2,  k0 = +2^75 (r~'^2 + A0_w),  ratio = -A2 / (1 - A1)   (rtk_device.hpp kLocalRatio)
+                    const double two75 = std::ldexp(1.0, 75);
+                    k0 = std::nextafter(static_cast<float>(two75 * (r2s + local_margin_const(r2s)) * (1.0 + 1e-6)), inf);     // rounded up: more candidates
+                    scaled = make_float4(static_cast<float>(-two75 * (1.0 - static_cast<double>(kLocalA1)) * sg * sg),      // s1
+                                         static_cast<float>(-2.0 * sg * kQuadRayScale),                                      // linear coefficient per unit of p
+                                         static_cast<float>(sg * sg), 0.f);
                     kind = 1;
                     uint16_t rows[32][16];
                     for (int rho = 0; rho < 32; ++rho) {
@@ -218,8 +226,9 @@ inline void prepare_scene(const rtk_scene* s, PreparedScene& out, bool compact =
             std::memcpy(&sk_f, &start_kind, 4);
             std::memcpy(&always_f, &always, 4);
             std::memcpy(&valid_f, &valid, 4);
-            out.lwdesc[2 * static_cast<size_t>(w)] = make_float4(sp.cxw, sp.cy, sp.czw, sigw);
-            out.lwdesc[2 * static_cast<size_t>(w) + 1] = make_float4(k0, sk_f, always_f, valid_f);
+            out.lwdesc[3 * static_cast<size_t>(w)] = make_float4(sp.cxw, sp.cy, sp.czw, 2.0f / sigw);          // |p| is clamped to 2 scaled units
+            out.lwdesc[3 * static_cast<size_t>(w) + 1] = make_float4(k0, sk_f, always_f, valid_f);
+            out.lwdesc[3 * static_cast<size_t>(w) + 2] = scaled;
         }
         out.local_words = words;
         // worth it when nearly every sphere sits in a class word (a kind-0 word costs a full vector-ALU word fed by scalar loads)
