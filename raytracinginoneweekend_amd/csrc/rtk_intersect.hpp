@@ -176,6 +176,9 @@ struct Intersector {
     }
 #endif
     // `n_exact`: the WAVE's running total of exact tests (every lane holds the same number).
+    // ALLOW_LOCAL = false (the grid walk's fallback for lanes the grid cannot serve): streamed scenes take the staged walk even
+    // when they have local tiles, so that the grid kernels do not carry the word-local walk's registers.
+    template <bool ALLOW_LOCAL = true>
     __device__ __forceinline__ void closest_hit(const Ray& r, bool active, float t_min, float t_max, float& t_out, int& idx_out,
                                                 uint32_t& n_exact) const {
         // Reference `a` (Sphere3.hpp:33), hoisted.
@@ -810,7 +813,7 @@ struct Intersector {
             // visible to its reads and the next chunk's writes cannot overtake this chunk's reads.
             // The next chunk is fetched into registers before the current one is scanned, so its
             // latency hides behind ~1150 filter instructions.
-            if (lwdesc != nullptr) {
+            if (ALLOW_LOCAL && lwdesc != nullptr) {
                 scan_local();
             } else {
                 constexpr int kPerLane = kStageSpheres / kWave;
@@ -932,7 +935,7 @@ struct Intersector {
         if (wave_any(brute)) {
             float t2;
             int i2;
-            closest_hit(r, brute, t_min, t_max, t2, i2, n_exact);
+            closest_hit<false>(r, brute, t_min, t_max, t2, i2, n_exact);
             if (brute) {
                 closest = t2;
                 best = i2;
