@@ -227,6 +227,43 @@ def test_local_frames_far_origins_do_not_take_every_sphere():
     assert flags.sum() < 3 * dp.sum() + 4 * m, (flags.sum(), dp.sum())
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, (0, 0, 0)), (1e-3, (0, 0, 0)), (1e3, (0, 0, 0)), (1.0, (1e4, -3e3, 500)), (1e-2, (50, 50, 50)), (3e4, (0, 0, 0)), (1e-5, (0, 0, 0))])
+def test_local_frames_scaled_and_translated_class_scenes(scale, offset):
+    """A class scene of 1500 random centres (so words are as wide as the scene: frames of sigma_w ~ 1/16 per unit of scale),
+    tiny, huge and far from the origin: sigma_w, the folded constants (2^75 sigma_w^2 ...) and the far-origin rule must hold
+    at every magnitude the cut admits (sigma_w in 2^-20 .. 2^20); beyond that a scene falls back to the staged walk."""
+    rng = np.random.default_rng(21)
+    s = _class_scene(rng, 1500, [(0.2, 0.2)], offset=offset, scale=scale)
+    e = Emul(s)
+    assert e.local_words() >= 40 or scale < 1e-4 or scale > 1e4
+    m = 2500
+    rays = np.zeros((m, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-12, 12, (m, 3)) * scale + np.array(offset)
+    rays[:, 3:6] = rng.normal(size=(m, 3)) * scale
+    rays[::9, 0:3] = (rng.uniform(-3000, 3000, (len(rays[::9]), 3)) * scale + np.array(offset)).astype(np.float32)      # far origins
+    check(s, rays)
+    check(s, tangent_rays(rng, s, 2000, 0.5 * scale, 5000 * scale, 1e-5))
+
+
+def test_local_frames_words_with_always_candidates_and_ragged_end():
+    """Non-filterable entries inside class runs (a giant, a NaN centre, a zero radius) are zero rows with their always bit;
+    the list ends in a ragged word."""
+    rng = np.random.default_rng(5)
+    s = _class_scene(rng, 1237, [(0.2, 0.2)])
+    order = np.argsort(s["cx"], kind="stable")                     # neighbours in the list are neighbours in space: narrow words
+    for k in s:
+        s[k] = s[k][order]
+    s["radius"][100] = 900.0; s["cy"][100] = -900.0                # a ground-like giant: peeled off the bounds, always a candidate
+    s["cx"][333] = np.nan
+    s["radius"][777] = 0.0
+    e = Emul(s)
+    assert e.local_words() >= 38
+    m = 3000
+    rays = np.concatenate([np.concatenate([rng.uniform(-12, 12, (m, 3)), rng.normal(size=(m, 3))], 1).astype(np.float32),
+                           tangent_rays(rng, {k: np.delete(v, [100, 333, 777]) for k, v in s.items()}, 1500, 0.5, 300, 1e-5)])
+    check(s, rays)
+
+
 def test_local_frames_mixed_scene_keeps_the_staged_walk():
     """Mixed radii: almost no word is a class word, the scene streams through the vector-ALU filter as before."""
     rng = np.random.default_rng(12)
