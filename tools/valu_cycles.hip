@@ -99,6 +99,19 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     X(v_fma_f32_clamp, asm volatile("v_fma_f32 %0, -%1, %2, %0 clamp" : "+v"(a[j]) : "v"(b), "v"(c)))                         \
     X(v_fma_f32_double_add, asm volatile("v_fma_f32 %0, %0, 2.0, %1" : "+v"(a[j]) : "v"(b)))                                 \
     X(v_cvt_u32_f32, asm volatile("v_cvt_u32_f32_e32 %0, %0" : "+v"(a[j])))                                                  \
+    X(v_cvt_pk_f16_f32_rtn, asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[j]) : "v"(b)))                               \
+    X(v_cvt_f32_f16, asm volatile("v_cvt_f32_f16_e32 %0, %0" : "+v"(a[j])))                                                  \
+    X(v_cvt_f32_f16_sdwa_hi, asm volatile("v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a[j])))   \
+    X(v_perm_b32_sgpr_sel, asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "s"(sb)))                         \
+    X(v_pk_mul_f32_sgpr, asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[j]) : "s"(sm[0])))                                  \
+    X(v_mov_b64, asm volatile("v_mov_b64_e32 %0, %1" : "+v"(p[j]) : "v"(pb)))                                                \
+    X(v_permlane32_swap, asm volatile("v_permlane32_swap_b32_e32 %0, %1" : "+v"(a[j]), "+v"(a[(j + 4) & 7])))                \
+    X(v_cndmask_b32_sgpr_mask, asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "s"(sm[0])))           \
+    X(v_addc_co_u32, asm volatile("v_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(a[j]) : : "vcc"))                            \
+    X(v_fmamk_f32, asm volatile("v_fmamk_f32 %0, %0, 0x3f7fff3f, %1" : "+v"(a[j]) : "v"(b)))                                 \
+    X(v_med3_f32_sgpr, asm volatile("v_med3_f32 %0, %0, -%1, %1" : "+v"(a[j]) : "s"(sb)))                                    \
+    X(v_subrev_f32_sgpr, asm volatile("v_subrev_f32_e32 %0, %1, %0" : "+v"(a[j]) : "s"(sb)))                                 \
+    X(v_lshl_or_b32_imm16, asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(a[j]) : "v"(b)))                               \
     X(mix_class_7, MIXC7(j))                                                                                                 \
     X(mix_class_clamp_7, MIXCC(j))                                                                                           \
     X(mix_class_sgpr_7, MIXCS(j))                                                                                            \
