@@ -129,6 +129,26 @@ def test_repeated_mixed_radii_frames_are_bit_identical():
     assert sg["rays"] == st0["rays"] and np.array_equal(bits(g), bits(first))
 
 
+def test_repeated_streamed_scene_frames_are_bit_identical_and_equal_the_grid():
+    """The same two checks for the WORD-LOCAL walk of scenes beyond LDS: the 10 001-sphere scene of BASELINE
+    configs[3], full-width frames, four workgroups per CU; its MFMAs go through the same asm statement as the LDS scenes'."""
+    ctx = rt.Context(0)
+    ctx.set_scene(rt.scaled_scene(k=50))
+    lay = ctx.scene_layout()
+    assert not lay["lds_resident"] and lay["class_words"] >= 300
+    W, H, spp = 1200, 800, 6
+    cam = rt.stock_camera(W / H)
+    first, st0 = ctx.render(cam, W, H, spp, 50, seed=5)
+    for _ in range(3):
+        img, st = ctx.render(cam, W, H, spp, 50, seed=5)
+        assert st["rays"] == st0["rays"] and st["exact_tests"] == st0["exact_tests"]
+        assert np.array_equal(bits(img), bits(first))
+    assert ctx.set_accel(rt.ACCEL_GRID) == rt.ACCEL_GRID
+    g, sg = ctx.render(cam, W, H, spp, 50, seed=5)
+    ctx.close()
+    assert sg["rays"] == st0["rays"] and np.array_equal(bits(g), bits(first))
+
+
 def test_large_general_scene_runs_eight_wave_workgroups_and_matches_the_grid():
     """1000 spheres of varied radius: 32 general words = 64 KiB of tiles; with four waves per workgroup only ONE workgroup fits
     a CU (113 KiB) and every SIMD is left a single wave, so rtk_set_scene picks the 8-wave instantiation of the render

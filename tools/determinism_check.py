@@ -1,7 +1,8 @@
-"""tools/determinism_check.py <frames> [--scene stock|mixed] [--grid] — renders the same 1200x800x60 frame <frames> times
+"""tools/determinism_check.py <frames> [--scene stock|mixed|scaled] [--grid] — renders the same 1200x800x60 frame <frames> times
 with the library named by RTK_LIB (or the in-tree one) and reports how many distinct images came out (the image is
 defined by pixel, sample and seed alone: one).  --scene mixed: 200 spheres of varied radius (general words, the loop the
-stock scene never enters).  --grid: one more frame through the uniform-grid kernel (no matrix instructions, another
+stock scene never enters); --scene scaled: the 10 001-sphere scene of BASELINE configs[3] at 8 spp (the word-local matrix-pipe
+walk of streamed scenes).  --grid: one more frame through the uniform-grid kernel (no matrix instructions, another
 code path to the same closest hits): it must equal the list walk's image bit for bit, which is what tells a
 deterministically WRONG list walk from a right one."""
 import hashlib, sys, os
@@ -10,9 +11,9 @@ import raytracinginoneweekend_amd as rt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 scene = sys.argv[sys.argv.index("--scene") + 1] if "--scene" in sys.argv else "stock"
 ctx = rt.Context(0)
-ctx.set_scene(rt.stock_scene() if scene == "stock" else rt.mixed_radii_scene(200))
+ctx.set_scene(rt.stock_scene() if scene == "stock" else rt.scaled_scene(k=50) if scene == "scaled" else rt.mixed_radii_scene(200))
 print("scene", scene, ctx.scene_layout(), flush=True)
-W, H, spp = 1200, 800, 60
+W, H, spp = 1200, 800, (8 if scene == "scaled" else 60)
 cam = rt.stock_camera(W / H)
 seen = {}
 for i in range(n):
