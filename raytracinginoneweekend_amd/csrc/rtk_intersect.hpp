@@ -120,6 +120,9 @@ struct Intersector {
 #ifdef RTK_PROFILE_SECTIONS
     mutable unsigned long long prof[4] = {0, 0, 0, 0};     // profile builds only (tools/build_variants.py name=-DRTK_PROFILE_SECTIONS=1): shader cycles in the filter, in the exact stage; streamed local walk: class words, kind-0 words, compaction (with early exact passes), final exact pass
 #endif
+#ifdef RTK_PROFILE_WORD
+    mutable unsigned long long wp[6] = {0, 0, 0, 0, 0, 0};     // profile builds only: parts of a class word of the streamed local walk
+#endif
 
     // `list_base`: list entries are 16-bit offsets from it (the list is flushed before an offset could overflow).
     __device__ __forceinline__ void flush(const Ray& r, float a, float t_min, int list_base, int& cnt, float& closest, int& best,
@@ -653,6 +656,9 @@ struct Intersector {
             // lanes the filter cannot judge take every sphere of a word, inactive lanes none: masks, set once per pass
             const uint32_t force_class = safe_ray ? 0u : 0xFFFFFFFFu, force_kind0 = safe ? 0u : 0xFFFFFFFFu, keep = active ? 0xFFFFFFFFu : 0u;
             for (int w = 0; w < words; ++w) {
+#ifdef RTK_PROFILE_WORD
+                const unsigned long long qtop = __builtin_readcyclecounter();
+#endif
                 const auto d0 = n0, d1 = n1, d2 = n2;
 #ifndef RTK_HOST_EMULATION
                 // scalar loads return out of order, so the only wait there is drains them all: wait for this word's descriptor
@@ -677,6 +683,10 @@ struct Intersector {
                 const int count = __builtin_popcount(__float_as_uint(d1.w));
                 const bool cls = (start_kind & 1) != 0;
                 const int base = start_kind >> 1;
+#ifdef RTK_PROFILE_WORD
+                const unsigned long long q0 = __builtin_readcyclecounter();
+                wp[0] += q0 - qtop;
+#endif
 #ifdef RTK_PROFILE_SECTIONS
                 const unsigned long long pw0 = __builtin_readcyclecounter();
 #endif
@@ -756,8 +766,18 @@ struct Intersector {
                     __builtin_memcpy(&b0, &g0, 16);
                     __builtin_memcpy(&b1, &g1, 16);
                     rtk_f32x16 t0, t1;
+#ifdef RTK_PROFILE_WORD
+                    const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
                     mfma_pair(t0, t1, a0, b0, b1);
+#ifdef RTK_PROFILE_WORD
+                    const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
                     m = mfma_join(mfma_bits16(t0, __uint_as_float(sw[0])), mfma_bits16(t1, __uint_as_float(sw[1])));
+#ifdef RTK_PROFILE_WORD
+                    const unsigned long long q3 = __builtin_readcyclecounter();
+                    wp[1] += q1 - q0; wp[2] += q2 - q1; wp[3] += q3 - q2; wp[5] += 1;
+#endif
 #endif
                     // Origins so far from the word that the reference's rounding noise (2^-19 |v|^2) rivals the squares the dot product
                     // is made of (a bounce off the far side of the ground sphere, seen from a short word's fine frame): the clamped
@@ -792,8 +812,14 @@ struct Intersector {
                 const unsigned long long pw1 = __builtin_readcyclecounter();
                 prof[cls ? 0 : 1] += pw1 - pw0;
 #endif
+#ifdef RTK_PROFILE_WORD
+                const unsigned long long q4 = __builtin_readcyclecounter();
+#endif
                 push(base, cand);
                 if ((w & 7) == 7 && wave_any(ecnt > kEntryCap - 8)) drain();
+#ifdef RTK_PROFILE_WORD
+                if (cls) wp[4] += __builtin_readcyclecounter() - q4;
+#endif
 #ifdef RTK_PROFILE_SECTIONS
                 prof[2] += __builtin_readcyclecounter() - pw1;
 #endif

@@ -234,6 +234,12 @@ __device__ __forceinline__ void render_wave(const RenderArgs& A, const Intersect
             }
         }
     }
+#ifdef RTK_PROFILE_WORD
+    if (lane == 0 && blockIdx.x < 2 && isect.wp[5])
+        printf("wave %d.%d: class words %llu  ticks per word: head (descriptor wait, prefetches) %.0f  rebuild %.0f  mfma statement %.0f  64 FMAs + join %.0f  push/check %.0f\n", static_cast<int>(blockIdx.x),
+               static_cast<int>(threadIdx.x / kWave), isect.wp[5], static_cast<double>(isect.wp[0]) / isect.wp[5], static_cast<double>(isect.wp[1]) / isect.wp[5], static_cast<double>(isect.wp[2]) / isect.wp[5],
+               static_cast<double>(isect.wp[3]) / isect.wp[5], static_cast<double>(isect.wp[4]) / isect.wp[5]);
+#endif
 #ifdef RTK_PROFILE_SECTIONS
     // profile builds only: where this wave's shader cycles went (wall cycles of the wave: its SIMD interleaves it with the others)
     if (lane == 0 && blockIdx.x < 3) {
