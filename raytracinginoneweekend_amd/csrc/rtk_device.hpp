@@ -160,7 +160,7 @@ struct SceneDev {
     int32_t filt_len = 0;            // float4 entries of filt
     int32_t filt_lds = 0;            // matrix-pipe layout: entries of filt that the kernels keep in LDS (all of it)
     // Streamed scenes whose words are (nearly) all class words in their OWN frame (local_term below): per word a 64-fragment
-    // tile and two float4 of descriptor; null when the scene streams through the vector-ALU filter alone.
+    // tile and three float4 of descriptor; null when the scene streams through the vector-ALU filter alone.
     // The list is cut into `lwords` words of at most 32 consecutive entries (rtk_scene_prep.hpp).
     const float4* ltiles = nullptr;  // [lwords][64]
     const float4* lwdesc = nullptr;  // [lwords][3]: (frame centre x, y, z, 2 / sigma_w) (k0, 2 * first entry + kind, always bits, valid bits: one per entry, from the top) (s1, -2 sigma_w 2^13, sigma_w^2, -): rtk_scene_prep.hpp
@@ -207,7 +207,7 @@ __host__ __device__ inline int tile_row_sphere(int rho) {
 // sigma_w r~ <= kLocalB.  With delta = sigma_w (C - c_w) (delta_y = 0), v = sigma_w (o - c_w), p = v - (v.d) d:
 //     P = qxx dx^2 + qzz dz^2 + qxz' dx dz - 2 px dx - 2 pz dz + |p|^2        (the class word's five monomials, cy' = 0)
 // The three quadratic coefficients are the ray's alone (built once per pass); the two linear ones and the constant depend on
-// the word: ~35 vector instructions per word rebuild their f16 parts and the constant, against the 192 that the
+// the word: ~45 vector instructions per word rebuild their f16 parts and the constant, against the 192 that the
 // vector-ALU form spends on the word's 32 tests beyond the 64 both need.  Term order of a local tile (local_term): the six
 // terms of the linear coefficients sit in B dwords lo[2], lo[3], hi[3], so that two lane swaps per word rebuild the B
 // operands.  Margin (all in the word's scaled units, u = 2^-24):
@@ -215,9 +215,10 @@ __host__ __device__ inline int tile_row_sphere(int rho) {
 //   the reference's own rounding: 2^-19 T1,  T1 = |v - delta|^2 + r'^2 <= 1.25 |v|^2 + 10 B^2 + r'^2
 //   v, v.d, p, |p|^2 in fp32: u |v| (28 |p| + 25) <= 2^-19 (0.5 |v|^2 + 0.81 |p|^2 + 0.64)
 //   => marg = 1.25 (sum) + 2^-21 = A0_w + kLocalA1 |p|^2 + kLocalA2 |v|^2,   K = |p|^2 - r~'^2 - marg.
-// |p| is clamped to 2 per component for the coefficients (|2 p| 2^13 must stay an f16 number): a clamped ray passes at
-// least 2 - sqrt(2) B > 1 from every centre of the word while r~'^2 + marg < B^2 + 0.1 for |v|^2 < kLocalSafeVV, so its
-// (wrong) sums are still positive; beyond kLocalSafeVV, or NaN, the word is judged as a whole (Intersector::closest_hit).
+// p is clamped to 2 per component for the coefficients (|2 p| 2^13 must stay an f16 number).  A clamped ray passes at least
+// 2 - sqrt(2) B > 1 from every centre of the word, and its (wrong) sum P_c = |delta_perp - p|^2 + 2 (p - p_c).delta is at
+// least a^2 + dx^2 - 4 dx >= 1.89 (a = |p_x| >= 2, |dx| <= B), while r~'^2 + marg < B^2 + 0.3 for |v|^2 < kLocalSafeVV: still
+// no candidate; beyond kLocalSafeVV, or NaN, the word is judged as a whole (Intersector::closest_hit).
 constexpr float kLocalB = 0.625f;
 constexpr float kLocalSafeVV = 0x1p14f;
 constexpr int kLocalShortRun = 8;           // class runs of at most this many entries go into kind-0 words (vector ALUs, one batch of scalar loads)

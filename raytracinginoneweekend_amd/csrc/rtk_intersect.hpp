@@ -558,7 +558,7 @@ struct Intersector {
 #endif
         };
         // Scenes beyond LDS whose words have local tiles (rtk_device.hpp "word-local frames"): per word the ray's linear
-        // coefficients and constant are rebuilt in the word's frame (~35 vector instructions), then the class word's two MFMAs
+        // coefficients and constant are rebuilt in the word's frame (~45 vector instructions), then the class word's two MFMAs
         // and 64 FMAs as above; the A fragment comes straight from global memory (16 bytes per lane, the next word's requested
         // a word ahead), the descriptor through the scalar cache.  Words without a tile (kind 0: mixed radii, the list's
         // ragged end) run the projection form on the vector ALUs with the spheres as scalar operands.
