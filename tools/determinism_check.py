@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracinginoneweekend_amd as rt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 scene = sys.argv[sys.argv.index("--scene") + 1] if "--scene" in sys.argv else "stock"
+depth = int(sys.argv[sys.argv.index("--depth") + 1]) if "--depth" in sys.argv else 50      # --depth N: which parts of the kernel other waves run (hazard studies)
 ctx = rt.Context(0)
 ctx.set_scene(rt.stock_scene() if scene == "stock" else rt.scaled_scene(k=50) if scene == "scaled" else rt.mixed_radii_scene(200))
 print("scene", scene, ctx.scene_layout(), flush=True)
@@ -17,14 +18,14 @@ W, H, spp = 1200, 800, (8 if scene == "scaled" else 60)
 cam = rt.stock_camera(W / H)
 seen = {}
 for i in range(n):
-    img, st = ctx.render(cam, W, H, spp, 50, seed=11)
+    img, st = ctx.render(cam, W, H, spp, depth, seed=11)
     h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
     seen[h] = seen.get(h, 0) + 1
     print(i, h, st["rays"], st["exact_tests"], st.get("samples"), st.get("lane_slots"), flush=True)
 ok = len(seen) == 1
 if "--grid" in sys.argv:
     assert ctx.set_accel(rt.ACCEL_GRID) == rt.ACCEL_GRID
-    img, st = ctx.render(cam, W, H, spp, 50, seed=11)
+    img, st = ctx.render(cam, W, H, spp, depth, seed=11)
     h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
     print("grid", h, st["rays"], flush=True)
     same = h in seen

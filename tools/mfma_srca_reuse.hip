@@ -7,7 +7,8 @@
 // checked }) and DISTURBER passes of one kind, chosen by the template parameter:
 //   0 none (plain FMAs)   1 global loads   2 global atomics without return   3 LDS reads and writes
 //   4 transcendentals (v_sqrt, v_rcp, v_sin, v_exp, v_log)   5 v_permlane32_swap   6 v_mad_u64_u32 + v_readlane/v_writelane
-//   7 all of them
+//   7 all of them   8 scalar memory loads (s_load through the constant address space)   9 s_memrealtime + s_sleep
+//   10 global atomics WITH return (the packet draw)   11 LDS atomics with return   12 kinds 8-11 together
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_srca_reuse.hip -o tools/bin/mfma_srca_reuse
 //   tools/bin/mfma_srca_reuse [workgroups per CU, default 4] [passes, default 4000]
 #include <hip/hip_runtime.h>
@@ -60,8 +61,13 @@ __global__ __launch_bounds__(256, 4) void k(unsigned long long* counts, Record* 
                 const f16x8 a = tiles[t * 64 + lane];
                 f32x16 d0, d1;
                 if (BETWEEN)
+#ifdef SAME_REGISTERS          // the register numbers of the failing render kernel (tools/hazard_hunt): D v[0:15], v[16:31]; A v[46:49]; B v[32:35], v[36:39]
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\ts_mov_b32 s60, s60\n\tv_mfma_f32_32x32x16_f16 %1, %2, %4, 0\n\ts_nop 15\n\ts_nop 3"
+                                 : "={v[0:15]}"(d0), "={v[16:31]}"(d1) : "{v[46:49]}"(a), "{v[32:35]}"(b0), "{v[36:39]}"(b1) : "s60");
+#else
                     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\ts_mov_b32 s60, s60\n\tv_mfma_f32_32x32x16_f16 %1, %2, %4, 0\n\ts_nop 15\n\ts_nop 3"
                                  : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b0), "v"(b1) : "s60");
+#endif
                 else
                     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_f16 %1, %2, %4, 0\n\ts_nop 15\n\ts_nop 3"
                                  : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b0), "v"(b1));
@@ -114,6 +120,26 @@ __global__ __launch_bounds__(256, 4) void k(unsigned long long* counts, Record* 
                     const u32x2 sw = __builtin_amdgcn_permlane32_swap(ifill, __float_as_uint(filler), false, false);
                     ifill ^= sw[1] >> 3;
                     filler = filler * 0.5f + static_cast<float>(sw[0] & 0xFFu);
+                }
+                if (KIND == 8 || KIND == 12) {          // scalar loads at a wave-uniform, changing address (K$ misses), as the descriptor and kernarg reads
+                    typedef const float __attribute__((address_space(4))) * CF;
+                    const uint32_t at = __builtin_amdgcn_readfirstlane((ifill >> 7) & 0x3FFF0u);
+                    const float sv = ((CF)(gbuf))[at] + ((CF)(gbuf))[at + 5];
+                    filler += sv;
+                    ifill = ifill * 1664525u + 1013904223u;
+                }
+                if (KIND == 9 || KIND == 12) {
+                    const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
+                    __builtin_amdgcn_s_sleep(1);
+                    ifill ^= static_cast<uint32_t>(tnow);
+                }
+                if (KIND == 10 || KIND == 12) {
+                    if (lane == 0) ifill += static_cast<uint32_t>(atomicAdd(gacc + 7, 1ull));
+                    ifill = __builtin_amdgcn_readfirstlane(ifill) + lane;
+                }
+                if (KIND == 11 || KIND == 12) {
+                    unsigned* q = reinterpret_cast<unsigned*>(lscratch);
+                    if (lane == (e & 63)) ifill += atomicAdd(q + (wave & 3), 1u);
                 }
                 if (KIND == 6 || KIND == 7) {
                     const uint64_t pr = static_cast<uint64_t>(0xD2511F53u) * ifill;
@@ -183,5 +209,10 @@ int main(int argc, char** argv) {
     run<6, true>("disturbers: mad_u64, read/writelane");
     run<7, true>("disturbers: all kinds");
     run<7, false>("disturbers: all kinds");
+    run<8, true>("disturbers: scalar memory loads");
+    run<9, true>("disturbers: s_memrealtime, s_sleep");
+    run<10, true>("disturbers: global atomic with return");
+    run<11, true>("disturbers: LDS atomic with return");
+    run<12, true>("disturbers: kinds 8-11");
     return 0;
 }
