@@ -20,6 +20,7 @@ seen = {}
 for i in range(n):
     img, st = ctx.render(cam, W, H, spp, depth, seed=11)
     h = hashlib.sha256(img.tobytes()).hexdigest()[:12]
+    h = h + ":" + str(st["exact_tests"]) if "--count-tests" in sys.argv else h      # --count-tests: a frame is (image, exact tests): for builds whose image is blank
     seen[h] = seen.get(h, 0) + 1
     print(i, h, st["rays"], st["exact_tests"], st.get("samples"), st.get("lane_slots"), flush=True)
 ok = len(seen) == 1
