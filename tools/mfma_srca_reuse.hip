@@ -9,6 +9,7 @@
 //   4 transcendentals (v_sqrt, v_rcp, v_sin, v_exp, v_log)   5 v_permlane32_swap   6 v_mad_u64_u32 + v_readlane/v_writelane
 //   7 all of them   8 scalar memory loads (s_load through the constant address space)   9 s_memrealtime + s_sleep
 //   10 global atomics WITH return (the packet draw)   11 LDS atomics with return   12 kinds 8-11 together
+//   13 per-lane divergent loops of IEEE square root and division on LDS operands (the exact stage)   14 kinds 5, 13 and f16 conversions (the coefficient build)
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_srca_reuse.hip -o tools/bin/mfma_srca_reuse
 //   tools/bin/mfma_srca_reuse [workgroups per CU, default 4] [passes, default 4000]
 #include <hip/hip_runtime.h>
@@ -141,6 +142,25 @@ __global__ __launch_bounds__(256, 4) void k(unsigned long long* counts, Record* 
                     unsigned* q = reinterpret_cast<unsigned*>(lscratch);
                     if (lane == (e & 63)) ifill += atomicAdd(q + (wave & 3), 1u);
                 }
+                if (KIND == 13 || KIND == 14) {          // lanes leave the loop one by one (partial EXEC), v_div_scale / v_div_fmas use VCC
+                    const int iters = 1 + static_cast<int>((ifill >> 5) & 7u);
+                    for (int q = 0; q < iters; ++q) {
+                        const float x = mine[((q + e) & 7) * 64 + (lane ^ q)] + 1.5f;
+                        const float disc = fabsf(filler) * x - 0.25f;
+                        if (disc > 0.0f) {
+                            const float sq = __builtin_sqrtf(disc);
+                            const float root = (-0.5f - sq) / x;
+                            if (root > -100.0f) filler = filler * 0.5f + root * 0.001f;
+                        }
+                    }
+                    ifill = ifill * 1664525u + 1013904223u;
+                }
+                if (KIND == 14) {
+                    const _Float16 h = static_cast<_Float16>(filler);
+                    const float back = static_cast<float>(h);
+                    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(filler - back), ifill, false, false);
+                    ifill ^= __builtin_amdgcn_perm(sw[0], sw[1], 0x05040100u);
+                }
                 if (KIND == 6 || KIND == 7) {
                     const uint64_t pr = static_cast<uint64_t>(0xD2511F53u) * ifill;
                     ifill = static_cast<uint32_t>(pr >> 32) ^ static_cast<uint32_t>(pr);
@@ -214,5 +234,7 @@ int main(int argc, char** argv) {
     run<10, true>("disturbers: global atomic with return");
     run<11, true>("disturbers: LDS atomic with return");
     run<12, true>("disturbers: kinds 8-11");
+    run<13, true>("disturbers: divergent IEEE sqrt / div loops");
+    run<14, true>("disturbers: 13 + conversions, lane swaps");
     return 0;
 }
